@@ -1,0 +1,214 @@
+/*
+ * goenv.h -- C-ABI of libgoenv.so, the MI355X (gfx950) batched 19x19 Go
+ * environment that replaces the per-game CPU hot path of ELF's DarkForest Go:
+ *
+ *   rules update   go/board.cc   TryPlay (:626-662) + Play (:1083-1179)
+ *   legal moves    go/board.cc   FindAllValidMoves (:763-779)
+ *   feature planes go/board_feature.cc  BoardFeature::Extract (:175-195)
+ *   scoring        go/board.cc   GetTrompTaylorScore (:1584-1688)
+ *
+ * Every board lives in HBM as one packed record (GOENV_REC_BYTES); one gfx950
+ * wavefront owns one board per launch.  All array arguments are DEVICE
+ * pointers (hipMalloc / torch-ROCm data_ptr()) unless a comment says "host".
+ * All launches are ordered on the caller's stream (`stream` = hipStream_t cast
+ * to void*, NULL = default stream).  No function synchronises the device
+ * except goenv_stats_host / goenv_last_error.
+ *
+ * Conventions shared with the reference:
+ *   action      = x*19 + y  (go/board.h:155 EXPORT_OFFSET_XY), -1 = pass
+ *                 (go/board_feature.h:67-71 Action2Coord(-1)=M_PASS),
+ *                 -2 = resign (go/common.h:41 M_RESIGN; never produced by
+ *                 Action2Coord, kept for completeness).
+ *   colour      = 0 empty, 1 black, 2 white   (go/common.h:34-36)
+ *   aug code    = rot (code%4: 0,CCW90,CCW180,CCW270) then flip (code>>2==1)
+ *                 (go/go_state.h:81-86, go/board_feature.h:38-48)
+ *
+ * Return value of every int function: 0 = ok, <0 = error (goenv_last_error()
+ * gives the text).  The library never aborts the process; the reference
+ * reports the same conditions by bool return or by the deliberate segfault in
+ * go/common.cc:36-48.
+ */
+#ifndef GOENV_H_
+#define GOENV_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GOENV_BOARD_SIZE 19
+#define GOENV_NUM_POINTS 361
+#define GOENV_NUM_PLANES 25                       /* go/board_feature.h:13 */
+#define GOENV_FEAT_FLOATS (25 * 361)              /* 9025 floats / board   */
+#define GOENV_NUM_SCALARS 16
+#define GOENV_NUM_STATS 16
+#define GOENV_REC_BYTES 2272                      /* packed board record   */
+
+#define GOENV_PASS (-1)
+#define GOENV_RESIGN (-2)
+
+/* indices into the int32 scalars[16] of the canonical view (goenv_get_state /
+ * goenv_set_state).  They mirror the Board fields of go/board.h:92-122. */
+enum {
+  GOENV_S_PLY = 0,       /* _ply, starts at 1                       */
+  GOENV_S_NEXT = 1,      /* _next_player                            */
+  GOENV_S_BCAP = 2,      /* _b_cap: stones captured BY black        */
+  GOENV_S_WCAP = 3,      /* _w_cap                                  */
+  GOENV_S_LAST1 = 4,     /* _last_move  as action (-1 pass)         */
+  GOENV_S_LAST2 = 5,
+  GOENV_S_LAST3 = 6,
+  GOENV_S_LAST4 = 7,
+  GOENV_S_KO_AGE = 8,    /* _ko_age (u16 arithmetic)                */
+  GOENV_S_KO = 9,        /* _simple_ko as action, -1 if never set   */
+  GOENV_S_KO_COLOR = 10, /* _simple_ko_color                        */
+  GOENV_S_DONE = 11,     /* ext: 1 = IsGameEnd (board.cc:1690), 2 = ply cap */
+  GOENV_S_GAME = 12,     /* ext: games finished on this slot (game_counter) */
+  GOENV_S_RSVD13 = 13,
+  GOENV_S_RSVD14 = 14,
+  GOENV_S_RSVD15 = 15
+};
+
+/* indices into the int64 stats[16] vector (end-of-episode statistics that the
+ * multi-GPU job all-reduces).  Slot 9 reduces with MAX, the rest
+ * with SUM. */
+enum {
+  GOENV_ST_GAMES = 0,
+  GOENV_ST_BLACK_WINS = 1,
+  GOENV_ST_WHITE_WINS = 2,
+  GOENV_ST_DRAWS = 3,
+  GOENV_ST_PLIES = 4,
+  GOENV_ST_BCAP = 5,
+  GOENV_ST_WCAP = 6,
+  GOENV_ST_SUM_LEN2 = 7,
+  GOENV_ST_PLY_CAP_HITS = 8,
+  GOENV_ST_MAX_LEN = 9,
+  GOENV_ST_SUM_SCORE = 10,
+  GOENV_ST_MOVES_APPLIED = 11,
+  GOENV_ST_ILLEGAL = 12
+};
+
+/* flags for goenv_ply */
+#define GOENV_F_RANDOM_POLICY 1u /* pick the move on device (cfg-2 policy)   */
+#define GOENV_F_AUTO_RESTART 2u  /* finished boards are scored, counted in the
+                                    stats vector and restarted in place      */
+#define GOENV_F_SKIP_DONE 4u     /* finished boards are left untouched       */
+
+typedef struct goenv_ctx goenv_ctx;
+
+/* Library / lifetime ------------------------------------------------------ */
+
+/* Version number of this ABI (GameContext::Version analogue,
+ * elf/pybind_interface.h:86). */
+int goenv_version(void);
+
+/* Text of the last error raised on the calling thread ("" if none).  host. */
+const char* goenv_last_error(void);
+
+/* Create n_boards empty boards on HIP device `device` (replaces the
+ * per-game `GoState` objects owned by GoGame, go/game.h:23-33 and the
+ * ClearBoard call in GoState::Reset, go/go_state.cc:89-91).
+ * board_id_base is the global id of board 0 (rank * n_boards in a sharded
+ * job): the on-device random policy is keyed by the GLOBAL id so results do
+ * not depend on the partition.  komi is used only for win statistics
+ * (default of the reference: 7.5, go/sgf.h:92).  max_ply = ply cap of the
+ * random playouts (0 = none). */
+int goenv_create(int device, int n_boards, uint64_t seed, int64_t board_id_base,
+                 float komi, int max_ply, goenv_ctx** out);
+int goenv_destroy(goenv_ctx* ctx);
+int goenv_num_boards(const goenv_ctx* ctx);
+/* device pointer to the packed records [n_boards][GOENV_REC_BYTES] */
+void* goenv_state_ptr(goenv_ctx* ctx);
+
+/* Reset / handicap ---------------------------------------------------------
+ * ClearBoard (go/board.cc:30-46) followed by HandicapTable::Apply
+ * (go/go_state.cc:61-70, PlaceHandicap go/board.cc:48-64) for the boards
+ * idx[0..n) (idx == NULL: all boards, n ignored).  handicap[i] in 0..9 (NULL:
+ * no handicap).  idx / handicap: device int32. */
+int goenv_reset(goenv_ctx* ctx, const int32_t* idx, int n, const int32_t* handicap,
+                void* stream);
+
+/* Canonical view -----------------------------------------------------------
+ * The observable part of `Board`: colours, per-stone group
+ * liberties and stones, last_placed of stones, and the scalars above.  Group
+ * ids, linked-list order and stale bytes are NOT part of it.  Arrays are in
+ * export order x*19+y, [n_boards][361]; scalars [n_boards][16].  Any output
+ * pointer may be NULL.  set_state rebuilds groups and liberties from colours
+ * (connected components) -- used to stage arbitrary positions. */
+int goenv_get_state(goenv_ctx* ctx, uint8_t* color, int16_t* liberties, int16_t* stones,
+                    uint16_t* last_placed, int32_t* scalars, void* stream);
+int goenv_set_state(goenv_ctx* ctx, const uint8_t* color, const uint16_t* last_placed,
+                    const int32_t* scalars, void* stream);
+
+/* Hot path -----------------------------------------------------------------
+ * goenv_step: GoState::forward (go/go_state.cc:73-78) = TryPlay2 + Play for
+ * every board: actions[b] is applied for the side to move; an illegal move
+ * leaves the board untouched and sets status[b] = 0 (legal: 1; the caller
+ * decides what an illegal move means, e.g. restart, go/game.cc:81-90).
+ * legal_out (u8 [n][361], may be NULL) receives FindAllValidMoves
+ * (go/board.cc:763-779) of the NEW position for the NEW side to move. */
+int goenv_step(goenv_ctx* ctx, const int64_t* actions, uint8_t* legal_out, int32_t* status_out,
+               void* stream);
+
+/* goenv_features: BoardFeature::Extract (go/board_feature.cc:175-195) of the
+ * current positions into float32 [n][25][19][19] (NCHW, inner index x'*19+y'
+ * after the D4 code, go/board_feature.h:80-91).  aug_codes: int32 [n] or NULL
+ * (code 0).  legal_out: optional legal mask of the current position (not
+ * augmented, export order). */
+int goenv_features(goenv_ctx* ctx, const int32_t* aug_codes, float* feat_out,
+                   uint8_t* legal_out, void* stream);
+
+/* goenv_ply: the fused per-ply hot path (one launch): choose (flag RANDOM:
+ * uniform over legal moves that do not fill an own true eye,
+ * go/board.cc:1501-1552, pass if none) or take actions[b]; apply it; then
+ * write the legal mask and the 25 planes of the new position straight into
+ * the batch buffers.  actions_out (int32 [n], may be NULL) receives the move
+ * applied (-1 pass, -3 = board was finished and skipped).  Any of legal_out /
+ * feat_out / status_out / aug_codes may be NULL. */
+int goenv_ply(goenv_ctx* ctx, uint32_t flags, const int64_t* actions, const int32_t* aug_codes,
+              float* feat_out, uint8_t* legal_out, int32_t* actions_out, int32_t* status_out,
+              void* stream);
+
+/* goenv_playout: random playouts to the end inside ONE persistent launch
+ * (state stays in LDS between plies); stops per board at game end or at the
+ * context's ply cap.  moves_out (int16 [n][max_record], may be NULL) records
+ * each board's move sequence for replay through the reference; nmoves_out
+ * int32 [n]. */
+int goenv_playout(goenv_ctx* ctx, int16_t* moves_out, int max_record, int32_t* nmoves_out,
+                  void* stream);
+
+/* goenv_score: GetTrompTaylorScore(board, NULL, NULL) (go/board.cc:1584-1688)
+ * into score_out float32 [n] (black minus white, no komi; 0 on an empty
+ * board); fast_out (may be NULL) = GetFastScore(board, RULE_CHINESE)
+ * (go/board.cc:1560-1582). */
+int goenv_score(goenv_ctx* ctx, float* score_out, float* fast_out, void* stream);
+
+/* Statistics ---------------------------------------------------------------
+ * goenv_finish: score every finished board that has not been counted yet and
+ * add it to the device stats vector (boards keep their state).
+ * goenv_stats_ptr: device int64[GOENV_NUM_STATS] -- this is the buffer a
+ * multi-GPU job hands to RCCL all-reduce (torch.distributed).  goenv_stats_host
+ * copies it to a host int64[16] (synchronises the stream). */
+int goenv_finish(goenv_ctx* ctx, void* stream);
+int64_t* goenv_stats_ptr(goenv_ctx* ctx);
+int goenv_stats_host(goenv_ctx* ctx, int64_t* out16_host, void* stream);
+int goenv_stats_clear(goenv_ctx* ctx, void* stream);
+
+/* Timing helper for bench.py: HIP events on the stream the kernels run on
+ * (torch.cuda.Event only sees torch's current stream).  goenv_timer_begin /
+ * _end bracket a region; goenv_timer_ms synchronises and returns its length. */
+int goenv_timer_begin(goenv_ctx* ctx, void* stream);
+int goenv_timer_end(goenv_ctx* ctx, void* stream);
+float goenv_timer_ms(goenv_ctx* ctx);
+
+/* D4 / action helpers (host, pure): go/board_feature.h:38-71.  Actions are
+ * export indices; goenv_aug_action maps a board action to the action index in
+ * the augmented frame (Coord2Action), goenv_aug_action_inv back
+ * (Action2Coord).  -1 stays -1. */
+int goenv_aug_action(int aug_code, int action);
+int goenv_aug_action_inv(int aug_code, int action);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOENV_H_ */

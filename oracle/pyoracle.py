@@ -1,0 +1,247 @@
+"""TEST INFRASTRUCTURE -- ctypes front-end to the two CPU checkers.
+
+* ``OracleBoard``  -> oracle/libgooracle.so (our plain-C restatement, go_oracle.c)
+* ``RefBoard``     -> oracle/_ref/libgoref.so (the unmodified reference compiled by
+  oracle/Makefile from /root/reference; present only where it was built)
+
+Both expose the same methods so tests can run one body against either.  Only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "libgooracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libgoref.so")
+
+NP_ = 361
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C")
+_i16p = np.ctypeslib.ndpointer(np.int16, flags="C")
+_u16p = np.ctypeslib.ndpointer(np.uint16, flags="C")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C")
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C")
+
+
+def _load(path, prefix):
+    lib = C.CDLL(path)
+
+    def f(name, res, *args):
+        fn = getattr(lib, prefix + name)
+        fn.restype = res
+        fn.argtypes = list(args)
+        return fn
+
+    api = {}
+    api["sizeof_board"] = f("sizeof_board", C.c_int)
+    api["clear"] = f("clear", None, C.c_void_p)
+    api["forward"] = f("forward", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int))
+    api["check_move"] = f("check_move", C.c_int, C.c_void_p, C.c_int)
+    api["place_handicap"] = f("place_handicap", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
+    api["apply_handicap"] = f("apply_handicap", None, C.c_void_p, C.c_int)
+    api["is_game_end"] = f("is_game_end", C.c_int, C.c_void_p)
+    api["canonical"] = f("canonical", None, C.c_void_p, _u8p, _i16p, _i16p, _u16p, _i32p)
+    api["legal"] = f("legal", C.c_int, C.c_void_p, _u8p)
+    api["candidates"] = f("candidates", C.c_int, C.c_void_p, _u8p)
+    api["extract"] = f("extract", None, C.c_void_p, C.c_int, _f32p)
+    api["tt_score"] = f("tt_score", C.c_float, C.c_void_p)
+    api["fast_score"] = f("fast_score", C.c_float, C.c_void_p, C.c_int)
+    api["policy_move"] = f("policy_move", C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64)
+    api["bench_playouts"] = f("bench_playouts", C.c_int64, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
+                              C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double))
+    return lib, api
+
+
+class _Board:
+    _lib = None
+    _api = None
+    _path = None
+    _prefix = None
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(cls._path)
+
+    @classmethod
+    def api(cls):
+        if cls._api is None:
+            if not cls.available():
+                raise RuntimeError("%s not built (run `make -C oracle`)" % cls._path)
+            cls._lib, cls._api = _load(cls._path, cls._prefix)
+            cls._post_load()
+        return cls._api
+
+    @classmethod
+    def _post_load(cls):
+        pass
+
+    def __init__(self):
+        a = self.api()
+        self._buf = C.create_string_buffer(a["sizeof_board"]() + 64)
+        self.ptr = C.cast(self._buf, C.c_void_p)
+        a["clear"](self.ptr)
+
+    def clone(self):
+        other = type(self).__new__(type(self))
+        other._buf = C.create_string_buffer(self._buf.raw, len(self._buf))
+        other.ptr = C.cast(other._buf, C.c_void_p)
+        return other
+
+    def clear(self):
+        self.api()["clear"](self.ptr)
+
+    def forward(self, action):
+        """GoState::forward: returns (legal, game_end)."""
+        end = C.c_int(0)
+        ok = self.api()["forward"](self.ptr, int(action), C.byref(end))
+        return bool(ok), bool(end.value)
+
+    def check_move(self, action):
+        return bool(self.api()["check_move"](self.ptr, int(action)))
+
+    def place_handicap(self, x, y, player=1):
+        return bool(self.api()["place_handicap"](self.ptr, x, y, player))
+
+    def apply_handicap(self, n):
+        self.api()["apply_handicap"](self.ptr, int(n))
+
+    def is_game_end(self):
+        return bool(self.api()["is_game_end"](self.ptr))
+
+    def canonical(self):
+        color = np.zeros(NP_, np.uint8)
+        libs = np.zeros(NP_, np.int16)
+        stones = np.zeros(NP_, np.int16)
+        lastp = np.zeros(NP_, np.uint16)
+        sc = np.zeros(16, np.int32)
+        self.api()["canonical"](self.ptr, color, libs, stones, lastp, sc)
+        return dict(color=color, liberties=libs, stones=stones, last_placed=lastp, scalars=sc)
+
+    def legal(self):
+        m = np.zeros(NP_, np.uint8)
+        self.api()["legal"](self.ptr, m)
+        return m
+
+    def candidates(self):
+        m = np.zeros(NP_, np.uint8)
+        self.api()["candidates"](self.ptr, m)
+        return m
+
+    def extract(self, aug=0):
+        out = np.zeros(25 * NP_, np.float32)
+        self.api()["extract"](self.ptr, int(aug), out)
+        return out
+
+    def tt_score(self):
+        return float(self.api()["tt_score"](self.ptr))
+
+    def fast_score(self, rule=0):
+        return float(self.api()["fast_score"](self.ptr, rule))
+
+    def policy_move(self, seed, board_id, game=0):
+        return int(self.api()["policy_move"](self.ptr, seed, board_id, game))
+
+    @classmethod
+    def bench_playouts(cls, n_boards, threads, seed, max_ply, with_features, games_per_board=1, budget_sec=0.0):
+        sec = C.c_double(0)
+        cs = C.c_double(0)
+        plies = cls.api()["bench_playouts"](n_boards, threads, seed, max_ply, int(with_features),
+                                            games_per_board, float(budget_sec), C.byref(sec), C.byref(cs))
+        return int(plies), float(sec.value)
+
+
+class OracleBoard(_Board):
+    _path = ORACLE_SO
+    _prefix = "goor_"
+
+    @classmethod
+    def _post_load(cls):
+        lib = cls._lib
+        lib.goor_set_state.restype = None
+        lib.goor_set_state.argtypes = [C.c_void_p, _u8p, _u16p, _i32p]
+        lib.goor_aug_action.restype = C.c_int
+        lib.goor_aug_action.argtypes = [C.c_int, C.c_int]
+        lib.goor_aug_action_inv.restype = C.c_int
+        lib.goor_aug_action_inv.argtypes = [C.c_int, C.c_int]
+        lib.goor_playout.restype = C.c_int
+        lib.goor_playout.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _i16p, C.c_int]
+
+    def set_state(self, color, last_placed, scalars):
+        self.api()
+        self._lib.goor_set_state(self.ptr, np.ascontiguousarray(color, np.uint8),
+                                 np.ascontiguousarray(last_placed, np.uint16),
+                                 np.ascontiguousarray(scalars, np.int32))
+
+    @classmethod
+    def aug_action(cls, code, action):
+        cls.api()
+        return cls._lib.goor_aug_action(code, action)
+
+    @classmethod
+    def aug_action_inv(cls, code, action):
+        cls.api()
+        return cls._lib.goor_aug_action_inv(code, action)
+
+    def playout(self, seed, board_id, game=0, max_ply=722):
+        moves = np.zeros(2048, np.int16)
+        n = self._lib.goor_playout(self.ptr, seed, board_id, game, max_ply, moves, 2048)
+        return moves[:n].copy()
+
+
+class RefBoard(_Board):
+    _path = REF_SO
+    _prefix = "goref_"
+
+    @classmethod
+    def _post_load(cls):
+        lib = cls._lib
+        lib.goref_coord2action.restype = C.c_int
+        lib.goref_coord2action.argtypes = [C.c_int, C.c_int]
+        lib.goref_action2coord.restype = C.c_int
+        lib.goref_action2coord.argtypes = [C.c_int, C.c_int]
+        lib.goref_num_groups.restype = C.c_int
+        lib.goref_num_groups.argtypes = [C.c_void_p]
+        lib.goref_sgf_load.restype = C.c_int
+        lib.goref_sgf_load.argtypes = [C.c_char_p, _i16p, _u8p, C.c_int, C.POINTER(C.c_int),
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+
+    @classmethod
+    def aug_action(cls, code, action):
+        cls.api()
+        return cls._lib.goref_coord2action(code, action)
+
+    @classmethod
+    def aug_action_inv(cls, code, action):
+        cls.api()
+        return cls._lib.goref_action2coord(code, action)
+
+    def num_groups(self):
+        return self._lib.goref_num_groups(self.ptr)
+
+    @classmethod
+    def sgf_load(cls, path):
+        cls.api()
+        moves = np.zeros(4096, np.int16)
+        players = np.zeros(4096, np.uint8)
+        nm, w, h, bs = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        n = cls._lib.goref_sgf_load(path.encode(), moves, players, 4096, C.byref(nm), C.byref(w),
+                                    C.byref(h), C.byref(bs))
+        if n < 0:
+            raise RuntimeError("reference Sgf::Load failed for " + path)
+        return dict(moves=moves[:n].copy(), players=players[:n].copy(), num_moves=nm.value,
+                    winner=w.value, handi=h.value, board_size=bs.value)
+
+
+def fnv_planes(h, planes):
+    """64-bit FNV-1a-style hash over the float bit patterns:
+    h = (h ^ u32) * 0x100000001b3, seed 0xcbf29ce484222325."""
+    u = np.ascontiguousarray(planes, np.float32).view(np.uint32)
+    prime = 0x100000001B3
+    mask = (1 << 64) - 1
+    for v in u.tolist():
+        h = ((h ^ v) * prime) & mask
+    return h
+
+
+FNV_SEED = 0xCBF29CE484222325
