@@ -1,0 +1,589 @@
+// goenv.hip -- kernels and C-ABI of libgoenv.so (see include/goenv.h).
+//
+// Launch shape: one 64-thread workgroup (= one wavefront) per board, so a batch of
+// B boards is B workgroups; __syncthreads() inside the device code lowers to a
+// wave-level fence.  All kernels are stream-ordered on the caller's stream.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/goenv.h"
+#include "goenv_device.h"
+
+using namespace goenv;
+
+// ----------------------------------------------------------------------------------------------
+// kernels
+// ----------------------------------------------------------------------------------------------
+
+struct PlyParams {
+  BoardRec* state;
+  int n;
+  uint32_t flags;
+  const int64_t* actions;
+  const int32_t* aug;
+  float* feat;
+  uint8_t* legal;
+  int32_t* actions_out;
+  int32_t* status;
+  unsigned long long* stats;
+  const float* lut;
+  uint64_t seed;
+  int64_t id_base;
+  float komi;
+  int max_ply;
+};
+
+// End-of-game accounting into the stats vector; lane 0 issues the atomics.
+__device__ __forceinline__ void account_game(unsigned long long* stats, int lane, const Scalars& s,
+                                             int score, float komi) {
+  if (lane == 0) {
+    const unsigned long long len = (unsigned long long)(s.ply - 1);
+    atomicAdd(&stats[GOENV_ST_GAMES], 1ull);
+    const float margin = (float)score - komi;
+    if (margin > 0.f) atomicAdd(&stats[GOENV_ST_BLACK_WINS], 1ull);
+    else if (margin < 0.f) atomicAdd(&stats[GOENV_ST_WHITE_WINS], 1ull);
+    else atomicAdd(&stats[GOENV_ST_DRAWS], 1ull);
+    atomicAdd(&stats[GOENV_ST_PLIES], len);
+    atomicAdd(&stats[GOENV_ST_BCAP], (unsigned long long)s.bcap);
+    atomicAdd(&stats[GOENV_ST_WCAP], (unsigned long long)s.wcap);
+    atomicAdd(&stats[GOENV_ST_SUM_LEN2], len * len);
+    if (s.done == 2) atomicAdd(&stats[GOENV_ST_PLY_CAP_HITS], 1ull);
+    atomicMax(&stats[GOENV_ST_MAX_LEN], len);
+    atomicAdd(&stats[GOENV_ST_SUM_SCORE], (unsigned long long)(long long)score);
+  }
+}
+
+// One ply for one board held in LDS/registers.  Returns the action applied (-1 pass) or
+// -4 if the external action was illegal (state untouched).
+template <bool RANDOM>
+__device__ __forceinline__ int ply_body(WaveLds& L, const Geo& g, int lane, uint32_t lab[KCH],
+                                        uint32_t lastp[KCH], Scalars& s, const PlyParams& P, int b) {
+  int a;
+  if (RANDOM) {
+    a = pick_random_move(L, g, lane, lab, s, P.seed, (uint64_t)(P.id_base + b));
+    a = __builtin_amdgcn_readfirstlane(a);
+  } else {
+    long long av = P.actions[b];
+    a = (av < -2 || av >= NPTS) ? -4 : (int)av;
+    a = __builtin_amdgcn_readfirstlane(a);
+    if (a >= 0 && !move_is_legal(L, s, a, s.next)) a = -4;
+    if (a == -4) return a;
+  }
+  if (a < 0) {
+    advance(s, a, s.next);  // pass / resign: Play's early return, go/board.cc:1092-1095
+  } else {
+    apply_move(L, g, lane, lab, lastp, s, a, s.next);
+  }
+  s.done = game_end(s) ? 1 : ((P.max_ply > 0 && s.ply > P.max_ply) ? 2 : 0);
+  s.counted = 0;
+  return a;
+}
+
+template <bool RANDOM>
+__global__ __launch_bounds__(64) void k_ply(PlyParams P) {
+  __shared__ WaveLds L;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (b >= P.n) return;
+  Geo g;
+  geo_init(g, lane);
+  BoardRec* rec = P.state + b;
+  Scalars s;
+  load_scalars(rec, s);
+  uint32_t lab[KCH], lastp[KCH];
+  load_board(rec, L, g, lane, lab, lastp);
+
+  bool skip = false;
+  if (s.done) {
+    if (P.flags & GOENV_F_AUTO_RESTART) {
+      if (!s.counted) account_game(P.stats, lane, s, tromp_taylor(L, g, lane, lab), P.komi);
+      clear_board_lds(L, g, lane, lab, lastp);
+      const int game = s.game + 1;
+      clear_scalars(s);
+      s.game = game;
+    } else if (P.flags & GOENV_F_SKIP_DONE) {
+      skip = true;
+    }
+  }
+  int a = -3;
+  if (!skip) {
+    a = ply_body<RANDOM>(L, g, lane, lab, lastp, s, P, b);
+    if (a != -4) store_board(rec, L, g, lane, lab, lastp, s);
+  }
+  if (lane == 0) {
+    if (P.actions_out) P.actions_out[b] = a;
+    if (P.status) P.status[b] = (a == -4) ? 0 : (a == -3 ? -1 : 1);
+  }
+  if (skip) return;
+  if (P.legal) write_legal(L, g, lab, s, P.legal + (size_t)b * NPTS);
+  if (P.feat) {
+    const int aug = P.aug ? (P.aug[b] & 7) : 0;
+    write_features(L, g, lane, lab, lastp, s, aug, P.lut, P.feat + (size_t)b * GOENV_FEAT_FLOATS);
+  }
+}
+
+__global__ __launch_bounds__(64) void k_features(const BoardRec* state, int n, const int32_t* aug_codes,
+                                                 const float* lut, float* feat, uint8_t* legal) {
+  __shared__ WaveLds L;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= n) return;
+  Geo g;
+  geo_init(g, lane);
+  const BoardRec* rec = state + b;
+  Scalars s;
+  load_scalars(rec, s);
+  uint32_t lab[KCH], lastp[KCH];
+  load_board(rec, L, g, lane, lab, lastp);
+  if (legal) write_legal(L, g, lab, s, legal + (size_t)b * NPTS);
+  if (feat) {
+    const int aug = aug_codes ? (aug_codes[b] & 7) : 0;
+    write_features(L, g, lane, lab, lastp, s, aug, lut, feat + (size_t)b * GOENV_FEAT_FLOATS);
+  }
+}
+
+__global__ __launch_bounds__(64) void k_score(const BoardRec* state, int n, float* tt, float* fast) {
+  __shared__ WaveLds L;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= n) return;
+  Geo g;
+  geo_init(g, lane);
+  const BoardRec* rec = state + b;
+  Scalars s;
+  load_scalars(rec, s);
+  uint32_t lab[KCH], lastp[KCH];
+  load_board(rec, L, g, lane, lab, lastp);
+  if (fast) {
+    int f = fast_score_cn(L, g, lab, s);
+    if (lane == 0) fast[b] = (float)f;
+  }
+  if (tt) {
+    int sc = tromp_taylor(L, g, lane, lab);
+    if (lane == 0) tt[b] = (float)sc;
+  }
+}
+
+// Handicap stones, go/go_state.cc:32-70: effective point lists per stone count ("*n" tokens
+// copy the n-stone list; the token itself decodes off-board and TryPlay rejects it).
+__constant__ int8_t c_handi_xy[9][2] = {{3, 3}, {15, 15}, {3, 15}, {15, 3}, {3, 9}, {15, 9}, {9, 15}, {9, 3}, {9, 9}};
+__constant__ int8_t c_handi_sets[10][10] = {
+    {-1}, {-1}, {0, 1, -1}, {0, 1, 3, -1}, {0, 1, 2, 3, -1}, {0, 1, 2, 3, 8, -1},
+    {0, 1, 2, 3, 4, 5, -1}, {0, 1, 2, 3, 4, 5, 8, -1}, {0, 1, 2, 3, 4, 5, 6, 7, -1},
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, -1}};
+
+__global__ __launch_bounds__(64) void k_reset(BoardRec* state, int n_boards, const int32_t* idx, int n,
+                                              const int32_t* handicap) {
+  __shared__ WaveLds L;
+  const int i = blockIdx.x, lane = threadIdx.x;
+  if (i >= n) return;
+  const int b = idx ? idx[i] : i;
+  if (b < 0 || b >= n_boards) return;
+  Geo g;
+  geo_init(g, lane);
+  BoardRec* rec = state + b;
+  Scalars s;
+  load_scalars(rec, s);
+  const int game = s.game;
+  uint32_t lab[KCH], lastp[KCH];
+  clear_board_lds(L, g, lane, lab, lastp);
+  clear_scalars(s);
+  s.game = game;
+  int h = handicap ? handicap[i] : 0;
+  h = __builtin_amdgcn_readfirstlane(h);
+  if (h >= 2 && h <= 9) {
+    for (int j = 0; j < 10; ++j) {
+      const int e = c_handi_sets[h][j];
+      if (e < 0) break;
+      const int p = c_handi_xy[e][0] * BS + c_handi_xy[e][1];
+      // PlaceHandicap, go/board.cc:48-64: TryPlay/Play as BLACK, then ply and last moves reset
+      if (s.ply <= 1 && move_is_legal(L, s, p, S_BLACK)) {
+        apply_move(L, g, lane, lab, lastp, s, p, S_BLACK);
+        s.ply = 1;
+        s.l1 = s.l2 = s.l3 = s.l4 = -1;
+      }
+    }
+  }
+  store_board(rec, L, g, lane, lab, lastp, s);
+}
+
+__global__ __launch_bounds__(64) void k_get_state(const BoardRec* state, int n, uint8_t* color, int16_t* libs,
+                                                  int16_t* stones, uint16_t* last_placed, int32_t* scalars) {
+  __shared__ WaveLds L;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= n) return;
+  Geo g;
+  geo_init(g, lane);
+  const BoardRec* rec = state + b;
+  Scalars s;
+  load_scalars(rec, s);
+  uint32_t lab[KCH], lastp[KCH];
+  load_board(rec, L, g, lane, lab, lastp);
+  // stones per root
+  GO_UNROLL
+  for (int k = 0; k < KCH; ++k)
+    if (g.p[k] < NPTS) L.desc[g.p[k]] = 0;
+  WSYNC();
+  GO_UNROLL
+  for (int k = 0; k < KCH; ++k)
+    if (g.p[k] < NPTS && lab[k]) atomicAdd(&L.desc[lab[k] & 511], 1u);
+  WSYNC();
+  const size_t o = (size_t)b * NPTS;
+  GO_UNROLL
+  for (int k = 0; k < KCH; ++k) {
+    const int p = g.p[k];
+    if (p < NPTS) {
+      const uint32_t v = lab[k];
+      if (color) color[o + p] = (uint8_t)(v >> 9);
+      if (libs) libs[o + p] = v ? (int16_t)L.lib[v & 511] : 0;
+      if (stones) stones[o + p] = v ? (int16_t)L.desc[v & 511] : 0;
+      if (last_placed) last_placed[o + p] = v ? (uint16_t)lastp[k] : 0;
+    }
+  }
+  if (scalars && lane < 16) {
+    int v = rec->sc[lane];
+    if (lane >= SC_COUNTED) v = 0;
+    scalars[(size_t)b * 16 + lane] = v;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_set_state(BoardRec* state, int n, const uint8_t* color,
+                                                  const uint16_t* last_placed, const int32_t* scalars) {
+  __shared__ WaveLds L;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= n) return;
+  Geo g;
+  geo_init(g, lane);
+  BoardRec* rec = state + b;
+  const size_t o = (size_t)b * NPTS;
+  uint32_t lab[KCH], lastp[KCH];
+  fill_rim(L, lane);
+  WSYNC();
+  GO_UNROLL
+  for (int k = 0; k < KCH; ++k) {
+    lab[k] = 0; lastp[k] = 0;
+    if (g.p[k] < NPTS) {
+      uint32_t col = color[o + g.p[k]];
+      col = (col == 1 || col == 2) ? col : 0;
+      lab[k] = col ? ((col << 9) | (uint32_t)g.p[k]) : 0u;
+      lastp[k] = last_placed ? last_placed[o + g.p[k]] : 0u;
+      L.lab[g.c[k]] = (uint16_t)lab[k];
+    }
+  }
+  WSYNC();
+  // connected components: min-label propagation to a fixed point (root = smallest member)
+  for (int iter = 0; iter < 2 * NPTS; ++iter) {
+    bool changed = false;
+    GO_UNROLL
+    for (int k = 0; k < KCH; ++k) {
+      if (g.p[k] < NPTS && lab[k]) {
+        uint32_t n4[4];
+        nbr4(L, g.c[k], n4);
+        uint32_t m = lab[k];
+        GO_UNROLL
+        for (int i = 0; i < 4; ++i)
+          if ((n4[i] >> 9) == (lab[k] >> 9) && n4[i] < m) m = n4[i];
+        if (m != lab[k]) { lab[k] = m; L.lab[g.c[k]] = (uint16_t)m; changed = true; }
+      }
+      WSYNC();
+    }
+    if (!__any(changed)) break;
+  }
+  rebuild_lib(L, g, lab);
+  Scalars s;
+  const int32_t* sc = scalars + (size_t)b * 16;
+  s.ply = sc[0]; s.next = sc[1]; s.bcap = sc[2]; s.wcap = sc[3];
+  s.l1 = sc[4]; s.l2 = sc[5]; s.l3 = sc[6]; s.l4 = sc[7];
+  s.koage = sc[8] & 0xffff; s.ko = sc[9]; s.kocolor = sc[10];
+  s.done = sc[11]; s.game = sc[12]; s.counted = 0;
+  store_board(rec, L, g, lane, lab, lastp, s);
+}
+
+__global__ __launch_bounds__(64) void k_finish(BoardRec* state, int n, unsigned long long* stats, float komi) {
+  __shared__ WaveLds L;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= n) return;
+  BoardRec* rec = state + b;
+  Scalars s;
+  load_scalars(rec, s);
+  if (!s.done || s.counted) return;
+  Geo g;
+  geo_init(g, lane);
+  uint32_t lab[KCH], lastp[KCH];
+  load_board(rec, L, g, lane, lab, lastp);
+  account_game(stats, lane, s, tromp_taylor(L, g, lane, lab), komi);
+  if (lane == 0) rec->sc[SC_COUNTED] = 1;
+}
+
+// Persistent random playout: the board stays in LDS/registers for the whole game.
+__global__ __launch_bounds__(64) void k_playout(PlyParams P, int16_t* moves, int max_record, int32_t* nmoves) {
+  __shared__ WaveLds L;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= P.n) return;
+  Geo g;
+  geo_init(g, lane);
+  BoardRec* rec = P.state + b;
+  Scalars s;
+  load_scalars(rec, s);
+  uint32_t lab[KCH], lastp[KCH];
+  load_board(rec, L, g, lane, lab, lastp);
+  int cnt = 0;
+  // exit condition every wave reaches: done flag, or the hard bound on iterations
+  for (int it = 0; it < 4096 && !s.done; ++it) {
+    int a = ply_body<true>(L, g, lane, lab, lastp, s, P, b);
+    if (moves && cnt < max_record && lane == 0) moves[(size_t)b * max_record + cnt] = (int16_t)a;
+    ++cnt;
+  }
+  store_board(rec, L, g, lane, lab, lastp, s);
+  if (nmoves && lane == 0) nmoves[b] = cnt;
+}
+
+// ----------------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------------
+
+struct goenv_ctx {
+  int device;
+  int n;
+  uint64_t seed;
+  int64_t id_base;
+  float komi;
+  int max_ply;
+  BoardRec* state;
+  unsigned long long* stats;
+  float* lut;
+  hipEvent_t ev0, ev1;
+};
+
+static thread_local std::string g_err;
+
+static int fail(const char* what, hipError_t e = hipSuccess) {
+  g_err = what;
+  if (e != hipSuccess) {
+    g_err += ": ";
+    g_err += hipGetErrorString(e);
+  }
+  return -1;
+}
+
+#define HIPCHK(x)                                  \
+  do {                                             \
+    hipError_t e_ = (x);                           \
+    if (e_ != hipSuccess) return fail(#x, e_);     \
+  } while (0)
+
+static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+extern "C" {
+
+int goenv_version(void) { return 1; }
+
+const char* goenv_last_error(void) { return g_err.c_str(); }
+
+int goenv_create(int device, int n_boards, uint64_t seed, int64_t board_id_base, float komi, int max_ply,
+                 goenv_ctx** out) {
+  if (!out) return fail("goenv_create: out is NULL");
+  *out = nullptr;
+  if (n_boards <= 0 || n_boards > (1 << 24)) return fail("goenv_create: n_boards out of range");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail("goenv_create: no such HIP device");
+  HIPCHK(hipSetDevice(device));
+  goenv_ctx* c = new goenv_ctx();
+  c->device = device; c->n = n_boards; c->seed = seed; c->id_base = board_id_base;
+  c->komi = komi; c->max_ply = max_ply;
+  c->state = nullptr; c->stats = nullptr; c->lut = nullptr;
+  hipError_t e;
+  if ((e = hipMalloc((void**)&c->state, (size_t)n_boards * sizeof(BoardRec))) != hipSuccess ||
+      (e = hipMalloc((void**)&c->stats, GOENV_NUM_STATS * sizeof(unsigned long long))) != hipSuccess ||
+      (e = hipMalloc((void**)&c->lut, HIST_LUT_N * sizeof(float))) != hipSuccess) {
+    if (c->state) (void)hipFree(c->state);
+    if (c->stats) (void)hipFree(c->stats);
+    delete c;
+    return fail("goenv_create: hipMalloc", e);
+  }
+  // GetHistoryExp, go/board_feature.cc:141: exp((last_placed - ply) / 10.0) in double, narrowed to
+  // float -- evaluated on the host with the same libm call so no device exp rounding enters.
+  static float lut[HIST_LUT_N];
+  for (int d = 0; d < HIST_LUT_N; ++d) lut[d] = (float)exp((double)(-d) / 10.0);
+  lut[HIST_LUT_N - 1] = 0.f;  // ages >= 2047 plies: exp(-204.7) underflows float to 0
+  HIPCHK(hipMemcpy(c->lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(c->stats, 0, GOENV_NUM_STATS * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(c->state, 0, (size_t)n_boards * sizeof(BoardRec)));
+  HIPCHK(hipEventCreate(&c->ev0));
+  HIPCHK(hipEventCreate(&c->ev1));
+  hipLaunchKernelGGL(k_reset, dim3(n_boards), dim3(64), 0, 0, c->state, n_boards, nullptr, n_boards, nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  *out = c;
+  return 0;
+}
+
+int goenv_destroy(goenv_ctx* c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(c->state);
+  (void)hipFree(c->stats);
+  (void)hipFree(c->lut);
+  (void)hipEventDestroy(c->ev0);
+  (void)hipEventDestroy(c->ev1);
+  delete c;
+  return 0;
+}
+
+int goenv_num_boards(const goenv_ctx* c) { return c ? c->n : 0; }
+void* goenv_state_ptr(goenv_ctx* c) { return c ? (void*)c->state : nullptr; }
+
+int goenv_reset(goenv_ctx* c, const int32_t* idx, int n, const int32_t* handicap, void* stream) {
+  if (!c) return fail("goenv_reset: ctx is NULL");
+  const int cnt = idx ? n : c->n;
+  if (cnt <= 0) return idx ? 0 : fail("goenv_reset: empty context");
+  if (idx && n > c->n) return fail("goenv_reset: n exceeds the number of boards");
+  hipLaunchKernelGGL(k_reset, dim3(cnt), dim3(64), 0, S(stream), c->state, c->n, idx, cnt, handicap);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int goenv_get_state(goenv_ctx* c, uint8_t* color, int16_t* liberties, int16_t* stones, uint16_t* last_placed,
+                    int32_t* scalars, void* stream) {
+  if (!c) return fail("goenv_get_state: ctx is NULL");
+  hipLaunchKernelGGL(k_get_state, dim3(c->n), dim3(64), 0, S(stream), c->state, c->n, color, liberties, stones,
+                     last_placed, scalars);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int goenv_set_state(goenv_ctx* c, const uint8_t* color, const uint16_t* last_placed, const int32_t* scalars,
+                    void* stream) {
+  if (!c) return fail("goenv_set_state: ctx is NULL");
+  if (!color || !scalars) return fail("goenv_set_state: color and scalars are required");
+  hipLaunchKernelGGL(k_set_state, dim3(c->n), dim3(64), 0, S(stream), c->state, c->n, color, last_placed, scalars);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static PlyParams make_params(goenv_ctx* c, uint32_t flags, const int64_t* actions, const int32_t* aug, float* feat,
+                             uint8_t* legal, int32_t* actions_out, int32_t* status) {
+  PlyParams P;
+  P.state = c->state; P.n = c->n; P.flags = flags; P.actions = actions; P.aug = aug; P.feat = feat;
+  P.legal = legal; P.actions_out = actions_out; P.status = status; P.stats = c->stats; P.lut = c->lut;
+  P.seed = c->seed; P.id_base = c->id_base; P.komi = c->komi; P.max_ply = c->max_ply;
+  return P;
+}
+
+int goenv_ply(goenv_ctx* c, uint32_t flags, const int64_t* actions, const int32_t* aug_codes, float* feat_out,
+              uint8_t* legal_out, int32_t* actions_out, int32_t* status_out, void* stream) {
+  if (!c) return fail("goenv_ply: ctx is NULL");
+  const bool random = flags & GOENV_F_RANDOM_POLICY;
+  if (!random && !actions) return fail("goenv_ply: actions required unless GOENV_F_RANDOM_POLICY is set");
+  PlyParams P = make_params(c, flags, actions, aug_codes, feat_out, legal_out, actions_out, status_out);
+  if (random) hipLaunchKernelGGL(k_ply<true>, dim3(c->n), dim3(64), 0, S(stream), P);
+  else hipLaunchKernelGGL(k_ply<false>, dim3(c->n), dim3(64), 0, S(stream), P);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int goenv_step(goenv_ctx* c, const int64_t* actions, uint8_t* legal_out, int32_t* status_out, void* stream) {
+  return goenv_ply(c, 0u, actions, nullptr, nullptr, legal_out, nullptr, status_out, stream);
+}
+
+int goenv_features(goenv_ctx* c, const int32_t* aug_codes, float* feat_out, uint8_t* legal_out, void* stream) {
+  if (!c) return fail("goenv_features: ctx is NULL");
+  if (!feat_out && !legal_out) return fail("goenv_features: no output buffer");
+  hipLaunchKernelGGL(k_features, dim3(c->n), dim3(64), 0, S(stream), c->state, c->n, aug_codes, c->lut, feat_out,
+                     legal_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int goenv_playout(goenv_ctx* c, int16_t* moves_out, int max_record, int32_t* nmoves_out, void* stream) {
+  if (!c) return fail("goenv_playout: ctx is NULL");
+  if (c->max_ply <= 0) return fail("goenv_playout: the context needs a ply cap (max_ply > 0)");
+  if (moves_out && max_record <= 0) return fail("goenv_playout: max_record must be positive");
+  PlyParams P = make_params(c, GOENV_F_RANDOM_POLICY, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL(k_playout, dim3(c->n), dim3(64), 0, S(stream), P, moves_out, max_record, nmoves_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int goenv_score(goenv_ctx* c, float* score_out, float* fast_out, void* stream) {
+  if (!c) return fail("goenv_score: ctx is NULL");
+  hipLaunchKernelGGL(k_score, dim3(c->n), dim3(64), 0, S(stream), c->state, c->n, score_out, fast_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int goenv_finish(goenv_ctx* c, void* stream) {
+  if (!c) return fail("goenv_finish: ctx is NULL");
+  hipLaunchKernelGGL(k_finish, dim3(c->n), dim3(64), 0, S(stream), c->state, c->n, c->stats, c->komi);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int64_t* goenv_stats_ptr(goenv_ctx* c) { return c ? (int64_t*)c->stats : nullptr; }
+
+int goenv_stats_host(goenv_ctx* c, int64_t* out16_host, void* stream) {
+  if (!c || !out16_host) return fail("goenv_stats_host: NULL argument");
+  HIPCHK(hipMemcpyAsync(out16_host, c->stats, GOENV_NUM_STATS * sizeof(int64_t), hipMemcpyDeviceToHost, S(stream)));
+  HIPCHK(hipStreamSynchronize(S(stream)));
+  return 0;
+}
+
+int goenv_stats_clear(goenv_ctx* c, void* stream) {
+  if (!c) return fail("goenv_stats_clear: ctx is NULL");
+  HIPCHK(hipMemsetAsync(c->stats, 0, GOENV_NUM_STATS * sizeof(int64_t), S(stream)));
+  return 0;
+}
+
+int goenv_timer_begin(goenv_ctx* c, void* stream) {
+  if (!c) return fail("goenv_timer_begin: ctx is NULL");
+  HIPCHK(hipEventRecord(c->ev0, S(stream)));
+  return 0;
+}
+int goenv_timer_end(goenv_ctx* c, void* stream) {
+  if (!c) return fail("goenv_timer_end: ctx is NULL");
+  HIPCHK(hipEventRecord(c->ev1, S(stream)));
+  return 0;
+}
+float goenv_timer_ms(goenv_ctx* c) {
+  if (!c) return -1.f;
+  float ms = -1.f;
+  if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.f;
+  if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.f;
+  return ms;
+}
+
+static int d4_fwd(int code, int x, int y) {
+  const int rot = code % 4;
+  const bool flip = (code >> 2) == 1;
+  int ox, oy;
+  if (rot == 1) { ox = y; oy = BS - x - 1; }
+  else if (rot == 2) { ox = BS - x - 1; oy = BS - y - 1; }
+  else if (rot == 3) { ox = BS - y - 1; oy = x; }
+  else { ox = x; oy = y; }
+  if (flip) { int t = ox; ox = oy; oy = t; }
+  return ox * BS + oy;
+}
+
+int goenv_aug_action(int aug_code, int action) {
+  if (action < 0 || action >= NPTS) return action;
+  return d4_fwd(aug_code, action / BS, action % BS);
+}
+
+int goenv_aug_action_inv(int aug_code, int action) {
+  if (action < 0 || action >= NPTS) return action;
+  int a = action / BS, b = action % BS;
+  if ((aug_code >> 2) == 1) { int t = a; a = b; b = t; }
+  const int rot = aug_code % 4;
+  int x, y;
+  if (rot == 1) { x = BS - 1 - b; y = a; }
+  else if (rot == 2) { x = BS - 1 - a; y = BS - 1 - b; }
+  else if (rot == 3) { x = b; y = BS - 1 - a; }
+  else { x = a; y = b; }
+  return x * BS + y;
+}
+
+}  // extern "C"

@@ -1,0 +1,238 @@
+"""ctypes binding of libgoenv.so (include/goenv.h) for Python callers.
+
+PyTorch is used only as the owner of device memory and streams: every array
+handed to the library is a torch-ROCm tensor's ``data_ptr()``.  There is no CPU
+fallback: if the HIP library is missing the import of :class:`GoEnv` raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgoenv.so")
+
+NUM_POINTS = 361
+NUM_PLANES = 25
+FEAT_FLOATS = NUM_PLANES * NUM_POINTS
+NUM_STATS = 16
+REC_BYTES = 2272
+PASS = -1
+RESIGN = -2
+
+F_RANDOM_POLICY = 1
+F_AUTO_RESTART = 2
+F_SKIP_DONE = 4
+
+# scalar slots of the canonical view
+S_PLY, S_NEXT, S_BCAP, S_WCAP, S_LAST1, S_LAST2, S_LAST3, S_LAST4, S_KO_AGE, S_KO, S_KO_COLOR, S_DONE, S_GAME = range(13)
+# stats slots
+(ST_GAMES, ST_BLACK_WINS, ST_WHITE_WINS, ST_DRAWS, ST_PLIES, ST_BCAP, ST_WCAP, ST_SUM_LEN2, ST_PLY_CAP_HITS,
+ ST_MAX_LEN, ST_SUM_SCORE, ST_MOVES_APPLIED, ST_ILLEGAL) = range(13)
+
+_lib = None
+
+_SIGS = {
+    "goenv_version": (C.c_int, []),
+    "goenv_last_error": (C.c_char_p, []),
+    "goenv_create": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_float, C.c_int, C.POINTER(C.c_void_p)]),
+    "goenv_destroy": (C.c_int, [C.c_void_p]),
+    "goenv_num_boards": (C.c_int, [C.c_void_p]),
+    "goenv_state_ptr": (C.c_void_p, [C.c_void_p]),
+    "goenv_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "goenv_get_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_void_p]),
+    "goenv_set_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 3 + [C.c_void_p]),
+    "goenv_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "goenv_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "goenv_ply": (C.c_int, [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6 + [C.c_void_p]),
+    "goenv_playout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "goenv_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "goenv_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "goenv_stats_ptr": (C.c_void_p, [C.c_void_p]),
+    "goenv_stats_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
+    "goenv_stats_clear": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "goenv_timer_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "goenv_timer_end": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "goenv_timer_ms": (C.c_float, [C.c_void_p]),
+    "goenv_aug_action": (C.c_int, [C.c_int, C.c_int]),
+    "goenv_aug_action_inv": (C.c_int, [C.c_int, C.c_int]),
+}
+
+
+def exported_symbols():
+    """Names include/goenv.h declares; tests check the .so exports each of them."""
+    return sorted(_SIGS)
+
+
+def load_library(path=LIB_PATH):
+    """Load libgoenv.so and attach signatures.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "libgoenv.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+            "there is no CPU fallback for the Go environment" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class GoEnvError(RuntimeError):
+    pass
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class GoEnv:
+    """n_boards concurrent 19x19 games resident in HBM on one GPU.
+
+    Mirrors what a `GoState` (go/go_state.h:31-110) offers per game -- forward,
+    CheckMove via the legal mask, Reset, ApplyHandicap, extractor(code).Extract --
+    for the whole batch at once.
+    """
+
+    def __init__(self, n_boards, device=0, seed=1, board_id_base=0, komi=7.5, max_ply=722):
+        self.lib = load_library()
+        self.n = int(n_boards)
+        self.device = torch.device("cuda", device)
+        self._h = C.c_void_p()
+        rc = self.lib.goenv_create(device, self.n, seed, board_id_base, komi, max_ply, C.byref(self._h))
+        self._chk(rc)
+
+    # -- plumbing ---------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            raise GoEnvError(self.lib.goenv_last_error().decode())
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, t, dtype, shape, name):
+        if t is None:
+            return
+        if t.device != self.device or t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+            raise GoEnvError("%s must be a contiguous %s tensor of shape %s on %s (got %s %s on %s)" % (
+                name, dtype, tuple(shape), self.device, t.dtype, tuple(t.shape), t.device))
+
+    def close(self):
+        if self._h:
+            self.lib.goenv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def new(self, dtype, *shape):
+        return torch.zeros((self.n,) + tuple(shape), dtype=dtype, device=self.device)
+
+    # -- API --------------------------------------------------------------
+    def reset(self, idx=None, handicap=None):
+        n = self.n
+        if idx is not None:
+            self._check(idx, torch.int32, (idx.numel(),), "idx")
+            n = idx.numel()
+        if handicap is not None:
+            self._check(handicap, torch.int32, (n,), "handicap")
+        self._chk(self.lib.goenv_reset(self._h, _ptr(idx), n, _ptr(handicap), self._stream()))
+
+    def get_state(self):
+        """Canonical view as a dict of device tensors."""
+        out = dict(color=self.new(torch.uint8, NUM_POINTS), liberties=self.new(torch.int16, NUM_POINTS),
+                   stones=self.new(torch.int16, NUM_POINTS), last_placed=self.new(torch.uint16, NUM_POINTS),
+                   scalars=self.new(torch.int32, 16))
+        self._chk(self.lib.goenv_get_state(self._h, _ptr(out["color"]), _ptr(out["liberties"]), _ptr(out["stones"]),
+                                           _ptr(out["last_placed"]), _ptr(out["scalars"]), self._stream()))
+        return out
+
+    def set_state(self, color, last_placed, scalars):
+        self._check(color, torch.uint8, (self.n, NUM_POINTS), "color")
+        self._check(last_placed, torch.uint16, (self.n, NUM_POINTS), "last_placed")
+        self._check(scalars, torch.int32, (self.n, 16), "scalars")
+        self._chk(self.lib.goenv_set_state(self._h, _ptr(color), _ptr(last_placed), _ptr(scalars), self._stream()))
+
+    def step(self, actions, legal_out=None, status_out=None):
+        self._check(actions, torch.int64, (self.n,), "actions")
+        self._check(legal_out, torch.uint8, (self.n, NUM_POINTS), "legal_out")
+        self._check(status_out, torch.int32, (self.n,), "status_out")
+        self._chk(self.lib.goenv_step(self._h, _ptr(actions), _ptr(legal_out), _ptr(status_out), self._stream()))
+
+    def features(self, feat_out=None, aug_codes=None, legal_out=None):
+        self._check(feat_out, torch.float32, (self.n, NUM_PLANES, 19, 19), "feat_out")
+        self._check(aug_codes, torch.int32, (self.n,), "aug_codes")
+        self._check(legal_out, torch.uint8, (self.n, NUM_POINTS), "legal_out")
+        self._chk(self.lib.goenv_features(self._h, _ptr(aug_codes), _ptr(feat_out), _ptr(legal_out), self._stream()))
+
+    def ply(self, flags=0, actions=None, aug_codes=None, feat_out=None, legal_out=None, actions_out=None,
+            status_out=None):
+        self._check(actions, torch.int64, (self.n,), "actions")
+        self._check(aug_codes, torch.int32, (self.n,), "aug_codes")
+        self._check(feat_out, torch.float32, (self.n, NUM_PLANES, 19, 19), "feat_out")
+        self._check(legal_out, torch.uint8, (self.n, NUM_POINTS), "legal_out")
+        self._check(actions_out, torch.int32, (self.n,), "actions_out")
+        self._check(status_out, torch.int32, (self.n,), "status_out")
+        self._chk(self.lib.goenv_ply(self._h, flags, _ptr(actions), _ptr(aug_codes), _ptr(feat_out), _ptr(legal_out),
+                                     _ptr(actions_out), _ptr(status_out), self._stream()))
+
+    def playout(self, moves_out=None, nmoves_out=None):
+        max_record = 0
+        if moves_out is not None:
+            max_record = moves_out.shape[1]
+            self._check(moves_out, torch.int16, (self.n, max_record), "moves_out")
+        self._check(nmoves_out, torch.int32, (self.n,), "nmoves_out")
+        self._chk(self.lib.goenv_playout(self._h, _ptr(moves_out), max_record, _ptr(nmoves_out), self._stream()))
+
+    def score(self, score_out=None, fast_out=None):
+        self._check(score_out, torch.float32, (self.n,), "score_out")
+        self._check(fast_out, torch.float32, (self.n,), "fast_out")
+        self._chk(self.lib.goenv_score(self._h, _ptr(score_out), _ptr(fast_out), self._stream()))
+
+    def finish(self):
+        self._chk(self.lib.goenv_finish(self._h, self._stream()))
+
+    def stats_tensor(self):
+        """The device int64[16] stats vector as a torch view (what the multi-GPU job all-reduces)."""
+        ptr = self.lib.goenv_stats_ptr(self._h)
+        # wrap foreign memory without copying: go through __cuda_array_interface__
+        holder = _CudaArray(ptr, (NUM_STATS,), "<i8", self)
+        return torch.as_tensor(holder, device=self.device)
+
+    def stats(self):
+        buf = (C.c_int64 * NUM_STATS)()
+        self._chk(self.lib.goenv_stats_host(self._h, buf, self._stream()))
+        return list(buf)
+
+    def stats_clear(self):
+        self._chk(self.lib.goenv_stats_clear(self._h, self._stream()))
+
+    def timer_begin(self):
+        self._chk(self.lib.goenv_timer_begin(self._h, self._stream()))
+
+    def timer_end(self):
+        self._chk(self.lib.goenv_timer_end(self._h, self._stream()))
+
+    def timer_ms(self):
+        return float(self.lib.goenv_timer_ms(self._h))
+
+
+class _CudaArray:
+    def __init__(self, ptr, shape, typestr, owner):
+        self.owner = owner
+        self.__cuda_array_interface__ = dict(shape=shape, typestr=typestr, data=(int(ptr), False), version=2)
+
+
+def aug_action(code, action):
+    return load_library().goenv_aug_action(code, action)
+
+
+def aug_action_inv(code, action):
+    return load_library().goenv_aug_action_inv(code, action)

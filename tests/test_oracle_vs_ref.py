@@ -1,0 +1,56 @@
+"""CPU: differential fuzz of the plain-C oracle against the unmodified reference build
+(oracle/_ref/libgoref.so).  Skipped where the reference build is absent."""
+import numpy as np
+import pytest
+
+from common import assert_canon_equal, assert_planes_equal
+from oracle.pyoracle import OracleBoard, RefBoard
+
+pytestmark = pytest.mark.skipif(not RefBoard.available(), reason="oracle/_ref/libgoref.so not built")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_games_with_passes_illegal_probes_and_handicap(seed):
+    rng = np.random.default_rng(seed)
+    for g in range(6):
+        r, o = RefBoard(), OracleBoard()
+        if g % 3 == 0:
+            h = int(rng.integers(0, 10))
+            r.apply_handicap(h)
+            o.apply_handicap(h)
+        fill_eyes = g % 2 == 0
+        for ply in range(650):
+            m = r.legal() if fill_eyes else r.candidates()
+            idx = np.flatnonzero(m)
+            u = rng.random()
+            if u < 0.02 or len(idx) == 0:
+                a = -1
+            elif u < 0.07:
+                a = int(rng.integers(0, 361))
+            else:
+                a = int(rng.choice(idx))
+            (lr, er), (lo, eo) = r.forward(a), o.forward(a)
+            assert (lr, er) == (lo, eo), (g, ply, a)
+            assert_canon_equal(r.canonical(), o.canonical(), "game %d ply %d" % (g, ply))
+            assert np.array_equal(r.legal(), o.legal()) and np.array_equal(r.candidates(), o.candidates())
+            if ply % 5 == 0:
+                aug = int(rng.integers(0, 8))
+                assert_planes_equal(r.extract(aug), o.extract(aug), "game %d ply %d aug %d" % (g, ply, aug))
+                assert r.tt_score() == o.tt_score()
+                assert r.fast_score(0) == o.fast_score(0) and r.fast_score(1) == o.fast_score(1)
+            if er and ply > 5:
+                break
+
+
+def test_policy_and_d4_agree():
+    for bid in range(4):
+        r, o = RefBoard(), OracleBoard()
+        for _ in range(120):
+            a = r.policy_move(99, bid, 3)
+            assert a == o.policy_move(99, bid, 3)
+            r.forward(a)
+            o.forward(a)
+    for code in range(8):
+        for a in range(361):
+            assert RefBoard.aug_action(code, a) == OracleBoard.aug_action(code, a)
+            assert RefBoard.aug_action_inv(code, a) == OracleBoard.aug_action_inv(code, a)
