@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- 19x19 Go moves/s of the MI355X batched Go environment (BASELINE.json metric).
+
+A "step" is ONE fused ply of the hot path over the whole batch resident in HBM: on-device
+cfg-2 policy (uniform over legal moves that do not fill an own true eye) -> rules update
+(TryPlay/Play) -> legal mask -> 25 feature planes written into the device batch buffers, one
+kernel launch.  Finished games are scored, counted into the stats vector and restarted in place
+(as ELF's selfplay restarts games, go/game.cc:81-90), so every step applies exactly one move on
+every board and value = n_gpus * boards * steps / time.
+
+Workload at N=1: BASELINE.json configs[1] -- 1,024 concurrent games, uniform-random legal-move
+playouts to the end, 1 MI355X.  For N>1 every rank runs the same per-GPU batch (weak scaling),
+boards keyed by global id; the only collective is the end-of-run stats all-reduce (RCCL).
+
+    python bench.py --gpus N --steps K --warmup W [--boards B]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+ALG_BYTES_PLANES = 25 * 361 * 4          # float32 planes written per board per ply
+ALG_BYTES_LEGAL = 361                    # u8 legal mask written per board per ply
+REC_BYTES = 1632                         # packed board record: read once + written once per ply
+ALG_BYTES_PER_BOARD = ALG_BYTES_PLANES + ALG_BYTES_LEGAL + 2 * REC_BYTES
+HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(budget_sec=12.0):
+    """The reference's own board.cc/board_feature.cc (oracle/_ref, kind "reference") -- or, when
+    that build did not travel, our C port of it (kind "port") -- driving the same cfg-2 workload
+    with Extract on every ply, on this host's cores.  Bounded sample."""
+    from oracle.pyoracle import OracleBoard, RefBoard
+    threads = max(1, min(16, os.cpu_count() or 1))
+    cls, kind = (RefBoard, "reference") if RefBoard.available() else (OracleBoard, "port")
+    n_boards = threads * 4      # each thread plays games back to back until the budget is spent
+    plies, sec = cls.bench_playouts(n_boards, threads, 1, 722, True, 1000000, budget_sec)
+    plies_nf, sec_nf = cls.bench_playouts(n_boards, threads, 1, 722, False, 1000000, budget_sec / 3)
+    return {
+        "value": plies / sec, "unit": "moves/s", "cores": threads, "kind": kind,
+        "sample": "cfg-2 policy playouts with BoardFeature::Extract on every ply, %d threads, "
+                  "%d plies in %.1f s (budget %.0f s)" % (threads, plies, sec, budget_sec),
+        "value_without_features": plies_nf / sec_nf,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--boards", type=int, default=1024, help="boards per GPU (cfg 2: 1024; cfg 4 shard: 8192)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run "
+                  "--nproc-per-node %d" % (args.gpus, world, args.gpus), file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+
+    from elf_amd import goenv
+    from elf_amd.sharding import reduce_stats
+
+    torch.cuda.set_device(local_rank)
+    B = args.boards
+    env = goenv.GoEnv(B, device=local_rank, seed=args.seed, board_id_base=rank * B, komi=7.5, max_ply=722)
+    feat = env.new(torch.float32, 25, 19, 19)
+    legal = env.new(torch.uint8, 361)
+    flags = goenv.F_RANDOM_POLICY | goenv.F_AUTO_RESTART
+
+    def step():
+        env.ply(flags, feat_out=feat, legal_out=legal)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    env.timer_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    env.timer_end()
+    torch.cuda.synchronize()
+    kernel_ms = env.timer_ms() / args.steps          # HIP events on the launch stream
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # end-of-episode statistics: count the games still in flight, then the one collective
+    env.finish()
+    stats = reduce_stats(env.stats_tensor()).cpu().tolist()
+
+    value = world * B * args.steps / elapsed
+    achieved = B * ALG_BYTES_PER_BOARD / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "19x19 Go moves/sec (node, 1/2/4/8 GPU) + feature-extract HBM GB/s",
+        "value": value, "unit": "moves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "i32 rules + f32 planes", "data": "synthetic",
+        "config": {"workload": "cfg2: %d concurrent 19x19 games per GPU, on-device uniform-random legal-move "
+                               "playouts to the end (restart in place), fused step + legal mask + 25 planes "
+                               "per ply" % B,
+                   "boards_per_gpu": B, "global_boards": world * B, "ply_cap": 722, "parallelism": "shard%d" % world},
+        "roofline": {"bound": "hbm", "kernel": "k_ply<random>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_per_board": ALG_BYTES_PER_BOARD, "kernel_ms": kernel_ms},
+        "feature_extract_GBps": achieved,
+        "stats": {"games": stats[0], "black_wins": stats[1], "white_wins": stats[2], "plies": stats[4],
+                  "max_len": stats[9], "ply_cap_hits": stats[8]},
+    }
+
+    if rank == 0 and world == 1 and not args.no_extra:
+        out["extra"] = extra_measurements(goenv, args.seed)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+    env.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def extra_measurements(goenv, seed):
+    """Not the headline: the same kernels at the cfg-4 per-GPU shard (8,192 boards) and larger,
+    the standalone feature kernel, and the persistent playout kernel."""
+    res = {}
+    for B in (8192, 65536):
+        env = goenv.GoEnv(B, seed=seed, max_ply=722)
+        feat, legal = env.new(torch.float32, 25, 19, 19), env.new(torch.uint8, 361)
+        flags = goenv.F_RANDOM_POLICY | goenv.F_AUTO_RESTART
+        steps = 300 if B == 8192 else 60
+        for _ in range(100 if B == 8192 else 150):   # into the middle game
+            env.ply(flags, feat_out=feat, legal_out=legal)
+        torch.cuda.synchronize()
+        env.timer_begin()
+        for _ in range(steps):
+            env.ply(flags, feat_out=feat, legal_out=legal)
+        env.timer_end()
+        ms = env.timer_ms() / steps
+        r = {"ply_ms": ms, "moves_per_s": B / (ms * 1e-3),
+             "ply_GBps": B * ALG_BYTES_PER_BOARD / (ms * 1e-3) / 1e9}
+        env.timer_begin()
+        for _ in range(steps):
+            env.features(feat, None, legal)
+        env.timer_end()
+        ms = env.timer_ms() / steps
+        r["features_ms"] = ms
+        r["features_GBps"] = B * (ALG_BYTES_PLANES + ALG_BYTES_LEGAL + REC_BYTES) / (ms * 1e-3) / 1e9
+        res["boards_%d" % B] = r
+        env.close()
+        del feat, legal
+    env = goenv.GoEnv(1024, seed=seed, max_ply=722)
+    nm = env.new(torch.int32)
+    env.playout(None, nm)
+    torch.cuda.synchronize()
+    env.reset()
+    env.timer_begin()
+    env.playout(None, nm)
+    env.timer_end()
+    ms = env.timer_ms()
+    res["persistent_playout_1024"] = {"ms": ms, "moves": int(nm.sum().item()),
+                                      "moves_per_s": float(nm.sum().item()) / (ms * 1e-3)}
+    env.close()
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -31,11 +31,25 @@ struct PlyParams {
   int32_t* status;
   unsigned long long* stats;
   const float* lut;
+  unsigned long long* stamps;  // diagnostic build only (GOENV_STAMPS): s_memtime per phase
   uint64_t seed;
   int64_t id_base;
   float komi;
   int max_ply;
 };
+
+#ifdef GOENV_STAMPS
+#define STAMP(i)                                                                   \
+  do {                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    unsigned long long t_ = __builtin_amdgcn_s_memtime();                          \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                            \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    if (P.stamps && threadIdx.x == 0) P.stamps[(size_t)blockIdx.x * 16 + (i)] = t_; \
+  } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 // End-of-game accounting into the stats vector; lane 0 issues the atomics.
 __device__ __forceinline__ void account_game(unsigned long long* stats, int lane, const Scalars& s,
@@ -58,19 +72,27 @@ __device__ __forceinline__ void account_game(unsigned long long* stats, int lane
 }
 
 // One ply for one board held in LDS/registers.  Returns the action applied (-1 pass) or
-// -4 if the external action was illegal (state untouched).
+// -4 if the external action was illegal (state untouched).  On return `m` holds the masks of
+// the new side to move.
 template <bool RANDOM>
 __device__ __forceinline__ int ply_body(WaveLds& L, const Geo& g, int lane, uint32_t lab[KCH],
-                                        uint32_t lastp[KCH], Scalars& s, const PlyParams& P, int b) {
+                                        uint32_t lastp[KCH], Scalars& s, Masks& m, const PlyParams& P, int b) {
   int a;
   if (RANDOM) {
-    a = pick_random_move(L, g, lane, lab, s, P.seed, (uint64_t)(P.id_base + b));
+    a = pick_random_move(m, lane, s, P.seed, (uint64_t)(P.id_base + b));
     a = __builtin_amdgcn_readfirstlane(a);
+    STAMP(2);
   } else {
     long long av = P.actions[b];
     a = (av < -2 || av >= NPTS) ? -4 : (int)av;
     a = __builtin_amdgcn_readfirstlane(a);
-    if (a >= 0 && !move_is_legal(L, s, a, s.next)) a = -4;
+    if (a >= 0) {  // TryPlay: the stored legal ballot of the side to move
+      unsigned long long w = 0;
+      GO_UNROLL
+      for (int k = 0; k < KCH; ++k)
+        if ((a >> 6) == k) w = m.legal[k];
+      if (!((w >> (a & 63)) & 1ull)) a = -4;
+    }
     if (a == -4) return a;
   }
   if (a < 0) {
@@ -78,6 +100,9 @@ __device__ __forceinline__ int ply_body(WaveLds& L, const Geo& g, int lane, uint
   } else {
     apply_move(L, g, lane, lab, lastp, s, a, s.next);
   }
+  STAMP(3);
+  unsigned long long eye[KCH];
+  move_masks(L, g, lab, s, s.next, m, eye);
   s.done = game_end(s) ? 1 : ((P.max_ply > 0 && s.ply > P.max_ply) ? 2 : 0);
   s.counted = 0;
   return a;
@@ -89,13 +114,17 @@ __global__ __launch_bounds__(64) void k_ply(PlyParams P) {
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
   if (b >= P.n) return;
+  STAMP(0);
   Geo g;
   geo_init(g, lane);
   BoardRec* rec = P.state + b;
   Scalars s;
   load_scalars(rec, s);
   uint32_t lab[KCH], lastp[KCH];
+  Masks m;
+  load_masks(rec, m);
   load_board(rec, L, g, lane, lab, lastp);
+  STAMP(1);
 
   bool skip = false;
   if (s.done) {
@@ -105,25 +134,30 @@ __global__ __launch_bounds__(64) void k_ply(PlyParams P) {
       const int game = s.game + 1;
       clear_scalars(s);
       s.game = game;
+      full_masks(m);
     } else if (P.flags & GOENV_F_SKIP_DONE) {
       skip = true;
     }
   }
   int a = -3;
   if (!skip) {
-    a = ply_body<RANDOM>(L, g, lane, lab, lastp, s, P, b);
-    if (a != -4) store_board(rec, L, g, lane, lab, lastp, s);
+    a = ply_body<RANDOM>(L, g, lane, lab, lastp, s, m, P, b);
+    STAMP(4);
+    if (a != -4) store_board(rec, g, lane, lab, lastp, m, s);
   }
+  STAMP(5);
   if (lane == 0) {
     if (P.actions_out) P.actions_out[b] = a;
     if (P.status) P.status[b] = (a == -4) ? 0 : (a == -3 ? -1 : 1);
   }
   if (skip) return;
-  if (P.legal) write_legal(L, g, lab, s, P.legal + (size_t)b * NPTS);
+  if (P.legal) write_legal(g, lane, m, P.legal + (size_t)b * NPTS);
+  STAMP(6);
   if (P.feat) {
     const int aug = P.aug ? (P.aug[b] & 7) : 0;
     write_features(L, g, lane, lab, lastp, s, aug, P.lut, P.feat + (size_t)b * GOENV_FEAT_FLOATS);
   }
+  STAMP(7);
 }
 
 __global__ __launch_bounds__(64) void k_features(const BoardRec* state, int n, const int32_t* aug_codes,
@@ -138,7 +172,11 @@ __global__ __launch_bounds__(64) void k_features(const BoardRec* state, int n, c
   load_scalars(rec, s);
   uint32_t lab[KCH], lastp[KCH];
   load_board(rec, L, g, lane, lab, lastp);
-  if (legal) write_legal(L, g, lab, s, legal + (size_t)b * NPTS);
+  if (legal) {
+    Masks m;
+    load_masks(rec, m);
+    write_legal(g, lane, m, legal + (size_t)b * NPTS);
+  }
   if (feat) {
     const int aug = aug_codes ? (aug_codes[b] & 7) : 0;
     write_features(L, g, lane, lab, lastp, s, aug, lut, feat + (size_t)b * GOENV_FEAT_FLOATS);
@@ -206,7 +244,10 @@ __global__ __launch_bounds__(64) void k_reset(BoardRec* state, int n_boards, con
       }
     }
   }
-  store_board(rec, L, g, lane, lab, lastp, s);
+  Masks m;
+  unsigned long long eye[KCH];
+  move_masks(L, g, lab, s, s.next, m, eye);
+  store_board(rec, g, lane, lab, lastp, m, s);
 }
 
 __global__ __launch_bounds__(64) void k_get_state(const BoardRec* state, int n, uint8_t* color, int16_t* libs,
@@ -221,6 +262,7 @@ __global__ __launch_bounds__(64) void k_get_state(const BoardRec* state, int n, 
   load_scalars(rec, s);
   uint32_t lab[KCH], lastp[KCH];
   load_board(rec, L, g, lane, lab, lastp);
+  rebuild_lib(L, g, lane, lab);  // exact liberty counts (the record keeps only min(lib,3))
   // stones per root
   GO_UNROLL
   for (int k = 0; k < KCH; ++k)
@@ -228,7 +270,7 @@ __global__ __launch_bounds__(64) void k_get_state(const BoardRec* state, int n, 
   WSYNC();
   GO_UNROLL
   for (int k = 0; k < KCH; ++k)
-    if (g.p[k] < NPTS && lab[k]) atomicAdd(&L.desc[lab[k] & 511], 1u);
+    if (g.p[k] < NPTS && lab[k]) atomicAdd(&L.desc[lab[k] & ROOT_MASK], 1u);
   WSYNC();
   const size_t o = (size_t)b * NPTS;
   GO_UNROLL
@@ -236,9 +278,9 @@ __global__ __launch_bounds__(64) void k_get_state(const BoardRec* state, int n, 
     const int p = g.p[k];
     if (p < NPTS) {
       const uint32_t v = lab[k];
-      if (color) color[o + p] = (uint8_t)(v >> 9);
-      if (libs) libs[o + p] = v ? (int16_t)L.lib[v & 511] : 0;
-      if (stones) stones[o + p] = v ? (int16_t)L.desc[v & 511] : 0;
+      if (color) color[o + p] = (uint8_t)col_of(v);
+      if (libs) libs[o + p] = v ? (int16_t)L.lib[v & ROOT_MASK] : 0;
+      if (stones) stones[o + p] = v ? (int16_t)L.desc[v & ROOT_MASK] : 0;
       if (last_placed) last_placed[o + p] = v ? (uint16_t)lastp[k] : 0;
     }
   }
@@ -284,21 +326,24 @@ __global__ __launch_bounds__(64) void k_set_state(BoardRec* state, int n, const 
         uint32_t m = lab[k];
         GO_UNROLL
         for (int i = 0; i < 4; ++i)
-          if ((n4[i] >> 9) == (lab[k] >> 9) && n4[i] < m) m = n4[i];
+          if (col_of(n4[i]) == col_of(lab[k]) && n4[i] < m) m = n4[i];
         if (m != lab[k]) { lab[k] = m; L.lab[g.c[k]] = (uint16_t)m; changed = true; }
       }
       WSYNC();
     }
     if (!__any(changed)) break;
   }
-  rebuild_lib(L, g, lab);
+  rebuild_lib(L, g, lane, lab);
   Scalars s;
   const int32_t* sc = scalars + (size_t)b * 16;
   s.ply = sc[0]; s.next = sc[1]; s.bcap = sc[2]; s.wcap = sc[3];
   s.l1 = sc[4]; s.l2 = sc[5]; s.l3 = sc[6]; s.l4 = sc[7];
   s.koage = sc[8] & 0xffff; s.ko = sc[9]; s.kocolor = sc[10];
   s.done = sc[11]; s.game = sc[12]; s.counted = 0;
-  store_board(rec, L, g, lane, lab, lastp, s);
+  Masks mk;
+  unsigned long long eye[KCH];
+  move_masks(L, g, lab, s, s.next, mk, eye);
+  store_board(rec, g, lane, lab, lastp, mk, s);
 }
 
 __global__ __launch_bounds__(64) void k_finish(BoardRec* state, int n, unsigned long long* stats, float komi) {
@@ -328,15 +373,17 @@ __global__ __launch_bounds__(64) void k_playout(PlyParams P, int16_t* moves, int
   Scalars s;
   load_scalars(rec, s);
   uint32_t lab[KCH], lastp[KCH];
+  Masks m;
+  load_masks(rec, m);
   load_board(rec, L, g, lane, lab, lastp);
   int cnt = 0;
   // exit condition every wave reaches: done flag, or the hard bound on iterations
   for (int it = 0; it < 4096 && !s.done; ++it) {
-    int a = ply_body<true>(L, g, lane, lab, lastp, s, P, b);
+    int a = ply_body<true>(L, g, lane, lab, lastp, s, m, P, b);
     if (moves && cnt < max_record && lane == 0) moves[(size_t)b * max_record + cnt] = (int16_t)a;
     ++cnt;
   }
-  store_board(rec, L, g, lane, lab, lastp, s);
+  store_board(rec, g, lane, lab, lastp, m, s);
   if (nmoves && lane == 0) nmoves[b] = cnt;
 }
 
@@ -471,6 +518,7 @@ static PlyParams make_params(goenv_ctx* c, uint32_t flags, const int64_t* action
   P.state = c->state; P.n = c->n; P.flags = flags; P.actions = actions; P.aug = aug; P.feat = feat;
   P.legal = legal; P.actions_out = actions_out; P.status = status; P.stats = c->stats; P.lut = c->lut;
   P.seed = c->seed; P.id_base = c->id_base; P.komi = c->komi; P.max_ply = c->max_ply;
+  P.stamps = nullptr;
   return P;
 }
 
@@ -485,6 +533,19 @@ int goenv_ply(goenv_ctx* c, uint32_t flags, const int64_t* actions, const int32_
   HIPCHK(hipGetLastError());
   return 0;
 }
+
+#ifdef GOENV_STAMPS
+// Diagnostic build only (libgoenv_diag.so, tools/stamps.py): per-board s_memtime stamps
+// [n][16] of one fused random ply.  Never part of libgoenv.so.
+extern "C" int goenv_diag_ply(goenv_ctx* c, uint32_t flags, float* feat_out, uint8_t* legal_out,
+                              unsigned long long* stamps, void* stream) {
+  PlyParams P = make_params(c, flags | GOENV_F_RANDOM_POLICY, nullptr, nullptr, feat_out, legal_out, nullptr, nullptr);
+  P.stamps = stamps;
+  hipLaunchKernelGGL(k_ply<true>, dim3(c->n), dim3(64), 0, S(stream), P);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+#endif
 
 int goenv_step(goenv_ctx* c, const int64_t* actions, uint8_t* legal_out, int32_t* status_out, void* stream) {
   return goenv_ply(c, 0u, actions, nullptr, nullptr, legal_out, nullptr, status_out, stream);

@@ -8,16 +8,23 @@
 // 21x21 `_infos` (go/board.h:80) -- so no edge tests are needed.
 //
 // State model (differs from the reference on purpose): every stone carries the
-// label (colour<<9 | root) where root is the point index of the most recently
-// added stone of its group.  Merging groups and removing captured groups are
-// therefore single lane-parallel relabel passes (replacing the linked-list
-// walks of MergeGroups/EmptyGroup, go/board.cc:559-593,412-434), and the
-// liberty table lib[root] is rebuilt from scratch each ply by letting every
-// empty point add 1 to each distinct neighbouring root with LDS atomics
-// (replacing the incremental bookkeeping of go/board.cc:393-409,529-555,
-// 595-620).  The reference's stored liberties always equal this from-scratch
-// count (VerifyBoard, go/board.cc:1455-1462), which is what makes the two
-// models observably identical.
+// 13-bit label  root | colour<<9 | cls<<11  where root is the point index of the
+// most recently added stone of its group and cls = min(liberties of the group, 3).
+// * Merging groups and removing captured groups are single lane-parallel relabel
+//   passes (replacing the linked-list walks of MergeGroups/EmptyGroup,
+//   go/board.cc:559-593,412-434).
+// * The liberty table lib[root] is rebuilt from scratch each ply: every empty
+//   point adds 1 to each distinct neighbouring root with LDS atomics (replacing
+//   the incremental bookkeeping of go/board.cc:393-409,529-555,595-620).  The
+//   reference's stored liberties always equal this from-scratch count
+//   (VerifyBoard, go/board.cc:1455-1462), so the two models are observably
+//   identical.
+// * Because every neighbour read returns colour AND liberty class, legality,
+//   eye and feature tests are branch-free table lookups on one LDS read per
+//   neighbour (no dependent group-table gather as in StoneLibertyAnalysis,
+//   go/board.cc:95-129).
+// * The legal mask and the playout-candidate mask of the side to move are
+//   computed once per ply and kept in the record as 2 x 361-bit ballots.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -30,29 +37,33 @@ constexpr int NPTS = 361;
 constexpr int PW = 21;       // padded width
 constexpr int KCH = 6;       // 64-lane chunks covering 361 points
 constexpr int LAB_N = 448;   // padded label image entries (441 used)
-constexpr int TAB_N = 368;   // per-point tables, 361 rounded up to 16 B of u16
+constexpr int TAB_N = 368;   // per-point tables, 361 rounded up
+constexpr int LIB_N = TAB_N + 64;  // + one atomic sink slot per lane
 constexpr int HIST_LUT_N = 2048;
 
 constexpr int S_EMPTY = 0, S_BLACK = 1, S_WHITE = 2;
 constexpr uint32_t BORDER = 3u << 9;
+constexpr uint32_t ROOT_MASK = 511u;
+constexpr uint32_t LABEL_MASK = 0x7ffu;  // root | colour
 constexpr int DIST_INF = 64;
 
 // scalar slots inside the record (same order as the canonical view, include/goenv.h)
 enum { SC_PLY = 0, SC_NEXT, SC_BCAP, SC_WCAP, SC_L1, SC_L2, SC_L3, SC_L4, SC_KOAGE, SC_KO,
        SC_KOCOLOR, SC_DONE, SC_GAME, SC_COUNTED, SC_R14, SC_R15 };
 
-// Packed per-board record in HBM: 2272 B, 16-B aligned, one contiguous read per wave.
+// Packed per-board record in HBM: 1632 B, 16-B aligned, one contiguous read per wave.
 struct __attribute__((aligned(16))) BoardRec {
-  uint16_t lab[TAB_N];    // colour<<9 | root, 0 = empty            (export order)
+  uint16_t lab[TAB_N];    // root | colour<<9 | cls<<11, 0 = empty       (export order)
   uint16_t lastp[TAB_N];  // ply of placement (go/board.h:46); stale under empties
-  uint16_t lib[TAB_N];    // liberties of the group whose root is this point
+  uint64_t legal[KCH];    // FindAllValidMoves of the side to move, bit p%64 of word p/64
+  uint64_t cand[KCH];     // legal AND NOT own true eye (cfg-2 playout policy)
   int32_t sc[16];
 };
-static_assert(sizeof(BoardRec) == 2272, "record layout");
+static_assert(sizeof(BoardRec) == 1632, "record layout");
 
-// Per-wave LDS working set (4.7 KB -> 32 waves/CU fit in 160 KB).
+// Per-wave LDS working set (~4.9 KB -> 32 waves/CU fit in 160 KB).
 struct WaveLds {
-  uint32_t lib[TAB_N];      // liberties by root
+  uint32_t lib[LIB_N];      // liberties by root (+ per-lane sink slots for masked atomics)
   uint32_t desc[TAB_N];     // per-point feature descriptor; also flood-fill scratch
   uint16_t lab[LAB_N];      // padded label image
   uint8_t dist[2][TAB_N];   // L1 distance to nearest black / white stone
@@ -64,13 +75,21 @@ struct Scalars {
 
 struct Geo {
   int p[KCH];  // point index (may be >= 361 in the last chunk)
-  int c[KCH];  // padded index, 0 (a rim cell) for invalid lanes
+  int c[KCH];  // padded index; an interior cell (never written) for invalid lanes
+};
+
+struct Masks {
+  unsigned long long legal[KCH];
+  unsigned long long cand[KCH];
 };
 
 #define GO_UNROLL _Pragma("unroll")
 #define WSYNC() __syncthreads()  // block == one wave: lowers to a wave-level fence
 
 __device__ __forceinline__ int popc64(unsigned long long v) { return __popcll(v); }
+__device__ __forceinline__ uint32_t col_of(uint32_t v) { return (v >> 9) & 3u; }
+__device__ __forceinline__ uint32_t cls_of(uint32_t v) { return (v >> 11) & 3u; }
+__device__ __forceinline__ uint32_t typ_of(uint32_t v) { return (v >> 9) & 15u; }  // colour | cls<<2
 
 __device__ __forceinline__ void geo_init(Geo& g, int lane) {
   GO_UNROLL
@@ -78,7 +97,7 @@ __device__ __forceinline__ void geo_init(Geo& g, int lane) {
     int p = lane + 64 * k;
     int x = p / BS, y = p - x * BS;
     g.p[k] = p;
-    g.c[k] = (p < NPTS) ? (x + 1) * PW + (y + 1) : 0;
+    g.c[k] = (p < NPTS) ? (x + 1) * PW + (y + 1) : PW + 1;
   }
 }
 
@@ -125,24 +144,23 @@ __device__ __forceinline__ void fill_rim(WaveLds& L, int lane) {
 // HBM record -> LDS image + registers.
 __device__ __forceinline__ void load_board(const BoardRec* rec, WaveLds& L, const Geo& g, int lane,
                                            uint32_t lab[KCH], uint32_t lastp[KCH]) {
-  uint32_t lb[KCH];
   GO_UNROLL
   for (int k = 0; k < KCH; ++k) {
     bool v = g.p[k] < NPTS;
     lab[k] = v ? rec->lab[g.p[k]] : 0u;
     lastp[k] = v ? rec->lastp[g.p[k]] : 0u;
-    lb[k] = v ? rec->lib[g.p[k]] : 0u;
   }
   fill_rim(L, lane);
   WSYNC();
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
-    if (g.p[k] < NPTS) {
-      L.lab[g.c[k]] = (uint16_t)lab[k];
-      L.lib[g.p[k]] = lb[k];
-    }
-  }
+  for (int k = 0; k < KCH; ++k)
+    if (g.p[k] < NPTS) L.lab[g.c[k]] = (uint16_t)lab[k];
   WSYNC();
+}
+
+__device__ __forceinline__ void load_masks(const BoardRec* rec, Masks& m) {
+  GO_UNROLL
+  for (int k = 0; k < KCH; ++k) { m.legal[k] = rec->legal[k]; m.cand[k] = rec->cand[k]; }
 }
 
 __device__ __forceinline__ void clear_board_lds(WaveLds& L, const Geo& g, int lane, uint32_t lab[KCH],
@@ -152,22 +170,37 @@ __device__ __forceinline__ void clear_board_lds(WaveLds& L, const Geo& g, int la
   GO_UNROLL
   for (int k = 0; k < KCH; ++k) {
     lab[k] = 0; lastp[k] = 0;
-    if (g.p[k] < NPTS) { L.lab[g.c[k]] = 0; L.lib[g.p[k]] = 0; }
+    if (g.p[k] < NPTS) L.lab[g.c[k]] = 0;
   }
   WSYNC();
 }
 
-__device__ __forceinline__ void store_board(BoardRec* rec, const WaveLds& L, const Geo& g, int lane,
-                                            const uint32_t lab[KCH], const uint32_t lastp[KCH],
-                                            const Scalars& s) {
+// masks of an empty board with BLACK to move: every point legal and a candidate
+__device__ __forceinline__ void full_masks(Masks& m) {
+  GO_UNROLL
+  for (int k = 0; k < KCH; ++k) {
+    unsigned long long w = (k < KCH - 1) ? ~0ull : ((1ull << (NPTS - 64 * (KCH - 1))) - 1ull);
+    m.legal[k] = w; m.cand[k] = w;
+  }
+}
+
+__device__ __forceinline__ void store_board(BoardRec* rec, const Geo& g, int lane, const uint32_t lab[KCH],
+                                            const uint32_t lastp[KCH], const Masks& m, const Scalars& s) {
   GO_UNROLL
   for (int k = 0; k < KCH; ++k) {
     if (g.p[k] < NPTS) {
       rec->lab[g.p[k]] = (uint16_t)lab[k];
       rec->lastp[g.p[k]] = (uint16_t)lastp[k];
-      rec->lib[g.p[k]] = (uint16_t)L.lib[g.p[k]];
     }
   }
+  // 12 mask words, one lane each
+  unsigned long long w = 0;
+  GO_UNROLL
+  for (int k = 0; k < KCH; ++k) {
+    if (lane == k) w = m.legal[k];
+    if (lane == KCH + k) w = m.cand[k];
+  }
+  if (lane < 2 * KCH) rec->legal[lane] = w;  // legal[6] and cand[6] are contiguous
   store_scalars(rec, s, lane);
 }
 
@@ -180,86 +213,95 @@ __device__ __forceinline__ void nbr4(const WaveLds& L, int c, uint32_t n[4]) {
   n[3] = L.lab[c + 1];
 }
 
-__device__ __forceinline__ bool is_stone(uint32_t v) { return v != 0 && v < BORDER; }
+__device__ __forceinline__ bool is_stone(uint32_t v) { uint32_t c = col_of(v); return c == 1 || c == 2; }
 
 // Liberty table from scratch: every empty point adds 1 to each DISTINCT neighbouring root
-// (== the distinct-liberty count RecomputeGroupLiberties produces, go/board.cc:595-620).
-__device__ __forceinline__ void rebuild_lib(WaveLds& L, const Geo& g, const uint32_t lab[KCH]) {
+// (== the distinct-liberty count RecomputeGroupLiberties produces, go/board.cc:595-620), then
+// every stone's cls bits are refreshed to min(liberties, 3).  Branch-free: masked-off adds go to
+// a per-lane sink slot.
+__device__ __forceinline__ void rebuild_lib(WaveLds& L, const Geo& g, int lane, uint32_t lab[KCH]) {
   GO_UNROLL
   for (int k = 0; k < KCH; ++k)
     if (g.p[k] < NPTS) L.lib[g.p[k]] = 0;
   WSYNC();
+  const int sink = TAB_N + lane;
   GO_UNROLL
   for (int k = 0; k < KCH; ++k) {
     if (g.p[k] < NPTS && lab[k] == 0) {
       uint32_t n[4];
       nbr4(L, g.c[k], n);
-      int r0 = is_stone(n[0]) ? (int)(n[0] & 511) : -1;
-      int r1 = is_stone(n[1]) ? (int)(n[1] & 511) : -1;
-      int r2 = is_stone(n[2]) ? (int)(n[2] & 511) : -1;
-      int r3 = is_stone(n[3]) ? (int)(n[3] & 511) : -1;
-      if (r0 >= 0) atomicAdd(&L.lib[r0], 1u);
-      if (r1 >= 0 && r1 != r0) atomicAdd(&L.lib[r1], 1u);
-      if (r2 >= 0 && r2 != r0 && r2 != r1) atomicAdd(&L.lib[r2], 1u);
-      if (r3 >= 0 && r3 != r0 && r3 != r1 && r3 != r2) atomicAdd(&L.lib[r3], 1u);
+      int r0 = is_stone(n[0]) ? (int)(n[0] & ROOT_MASK) : sink;
+      int r1 = is_stone(n[1]) ? (int)(n[1] & ROOT_MASK) : sink;
+      int r2 = is_stone(n[2]) ? (int)(n[2] & ROOT_MASK) : sink;
+      int r3 = is_stone(n[3]) ? (int)(n[3] & ROOT_MASK) : sink;
+      r1 = (r1 == r0) ? sink : r1;
+      r2 = (r2 == r0 || r2 == r1) ? sink : r2;
+      r3 = (r3 == r0 || r3 == r1 || r3 == r2) ? sink : r3;
+      atomicAdd(&L.lib[r0], 1u);
+      atomicAdd(&L.lib[r1], 1u);
+      atomicAdd(&L.lib[r2], 1u);
+      atomicAdd(&L.lib[r3], 1u);
+    }
+  }
+  WSYNC();
+  GO_UNROLL
+  for (int k = 0; k < KCH; ++k) {
+    if (g.p[k] < NPTS && lab[k] != 0) {
+      uint32_t lib = L.lib[lab[k] & ROOT_MASK];
+      uint32_t v = (lab[k] & LABEL_MASK) | ((lib > 3u ? 3u : lib) << 11);
+      lab[k] = v;
+      L.lab[g.c[k]] = (uint16_t)v;
     }
   }
   WSYNC();
 }
 
-// Legal mask (FindAllValidMoves, go/board.cc:763-779: empty, not a simple-ko violation
-// :156-161, not suicide :131-154) and own-true-eye mask (IsTrueEye :1501-1552) for `player`.
-template <bool WANT_EYE>
+// 16-entry truth tables over typ = colour | cls<<2 of a neighbour.
+//   OK   : neighbour makes the move non-suicidal (IsSuicideMove go/board.cc:131-154):
+//          empty, own group with > 1 liberty, or enemy group with exactly 1 liberty
+//   OWNR : neighbour is own stone or rim (IsEye go/board.cc:1501-1508)
+__device__ __forceinline__ uint32_t tab_ok(int player) {
+  // typ bits: colour in 0..1, cls in 2..3.  empty: typ 0.
+  uint32_t t = 1u << 0;
+  const uint32_t own = (uint32_t)player, opp = 3u - own;
+  t |= (1u << (own | (2u << 2))) | (1u << (own | (3u << 2)));
+  t |= 1u << (opp | (1u << 2));
+  return t;
+}
+__device__ __forceinline__ uint32_t tab_col(uint32_t colour) {  // any cls
+  return (1u << colour) | (1u << (colour | 4u)) | (1u << (colour | 8u)) | (1u << (colour | 12u));
+}
+
+// Legal mask (FindAllValidMoves, go/board.cc:763-779: empty, not a simple-ko violation :156-161,
+// not suicide :131-154) and own-true-eye mask (IsTrueEye :1501-1552) for `player`, as ballots.
 __device__ __forceinline__ void move_masks(const WaveLds& L, const Geo& g, const uint32_t lab[KCH],
-                                           const Scalars& s, int player, bool legal[KCH], bool eye[KCH]) {
-  const uint32_t opp = 3u - (uint32_t)player;
+                                           const Scalars& s, int player, Masks& m,
+                                           unsigned long long eye_w[KCH]) {
+  const uint32_t OK = tab_ok(player);
+  const uint32_t OWNR = tab_col((uint32_t)player) | tab_col(3u);
+  const uint32_t OPP = tab_col(3u - (uint32_t)player);
+  const uint32_t RIM = tab_col(3u);
   const int ko_p = (s.koage == 0 && s.kocolor == player) ? s.ko : -1;
   GO_UNROLL
   for (int k = 0; k < KCH; ++k) {
-    bool ok = false, e = false;
-    if (g.p[k] < NPTS && lab[k] == 0) {
-      uint32_t n[4];
-      nbr4(L, g.c[k], n);
-      bool all_own = true;
-      GO_UNROLL
-      for (int i = 0; i < 4; ++i) {
-        uint32_t col = n[i] >> 9;
-        if (n[i] == 0) { ok = true; all_own = false; }
-        else if (col == (uint32_t)player) { if (L.lib[n[i] & 511] > 1) ok = true; }
-        else if (col == opp) { all_own = false; if (L.lib[n[i] & 511] == 1) ok = true; }
-      }
-      if (g.p[k] == ko_p) ok = false;
-      if (WANT_EYE && all_own) {
-        int c = g.c[k];
-        uint32_t d0 = L.lab[c - PW - 1] >> 9, d1 = L.lab[c - PW + 1] >> 9;
-        uint32_t d2 = L.lab[c + PW - 1] >> 9, d3 = L.lab[c + PW + 1] >> 9;
-        int n_opp = (d0 == opp) + (d1 == opp) + (d2 == opp) + (d3 == opp);
-        int n_rim = (d0 == 3) + (d1 == 3) + (d2 == 3) + (d3 == 3);
-        bool fake = (n_rim > 0 && n_opp >= 1) || (n_rim == 0 && n_opp >= 2);
-        e = !fake;
-      }
-    }
-    legal[k] = ok;
-    eye[k] = e;
+    const int c = g.c[k];
+    uint32_t n[4];
+    nbr4(L, c, n);
+    const uint32_t d0 = typ_of(L.lab[c - PW - 1]), d1 = typ_of(L.lab[c - PW + 1]);
+    const uint32_t d2 = typ_of(L.lab[c + PW - 1]), d3 = typ_of(L.lab[c + PW + 1]);
+    const uint32_t t0 = typ_of(n[0]), t1 = typ_of(n[1]), t2 = typ_of(n[2]), t3 = typ_of(n[3]);
+    const bool empty = g.p[k] < NPTS && lab[k] == 0;
+    const uint32_t ok = ((OK >> t0) | (OK >> t1) | (OK >> t2) | (OK >> t3)) & 1u;
+    const uint32_t all_own = (OWNR >> t0) & (OWNR >> t1) & (OWNR >> t2) & (OWNR >> t3) & 1u;
+    const int n_opp = (int)(((OPP >> d0) & 1u) + ((OPP >> d1) & 1u) + ((OPP >> d2) & 1u) + ((OPP >> d3) & 1u));
+    const int n_rim = (int)(((RIM >> d0) & 1u) + ((RIM >> d1) & 1u) + ((RIM >> d2) & 1u) + ((RIM >> d3) & 1u));
+    const bool fake = n_rim > 0 ? n_opp >= 1 : n_opp >= 2;  // IsFakeEye go/board.cc:1530-1544
+    const bool legal = empty && ok && g.p[k] != ko_p;
+    const bool eye = empty && all_own && !fake;
+    m.legal[k] = __ballot(legal);
+    eye_w[k] = __ballot(eye);
+    m.cand[k] = m.legal[k] & ~eye_w[k];
   }
-}
-
-// Legality of one move for `player` (TryPlay, go/board.cc:626-662).  Wave-uniform.
-__device__ __forceinline__ bool move_is_legal(const WaveLds& L, const Scalars& s, int p, int player) {
-  const int c = pad_of(p);
-  if (L.lab[c] != 0) return false;
-  if (s.ko == p && s.koage == 0 && s.kocolor == player) return false;
-  uint32_t n[4];
-  nbr4(L, c, n);
-  bool ok = false;
-  GO_UNROLL
-  for (int i = 0; i < 4; ++i) {
-    uint32_t col = n[i] >> 9;
-    if (n[i] == 0) ok = true;
-    else if (col == (uint32_t)player) { if (L.lib[n[i] & 511] > 1) ok = true; }
-    else if (col == 3u - (uint32_t)player) { if (L.lib[n[i] & 511] == 1) ok = true; }
-  }
-  return ok;
 }
 
 // update_next_move, go/board.cc:1014-1027
@@ -274,7 +316,21 @@ __device__ __forceinline__ bool game_end(const Scalars& s) {
   return s.ply > 1 && ((s.l1 == -1 && s.l2 == -1) || s.l1 == -2);
 }
 
-// Play (go/board.cc:1083-1179) of a LEGAL board move p for `player`.
+// Legality of one board move for `player` from the image (TryPlay, go/board.cc:626-662).
+// Wave-uniform.  Used where the stored masks do not apply (handicap stones are BLACK's
+// whoever is to move).
+__device__ __forceinline__ bool move_is_legal(const WaveLds& L, const Scalars& s, int p, int player) {
+  const int c = pad_of(p);
+  if (L.lab[c] != 0) return false;
+  if (s.ko == p && s.koage == 0 && s.kocolor == player) return false;
+  uint32_t n[4];
+  nbr4(L, c, n);
+  const uint32_t OK = tab_ok(player);
+  return (((OK >> typ_of(n[0])) | (OK >> typ_of(n[1])) | (OK >> typ_of(n[2])) | (OK >> typ_of(n[3]))) & 1u) != 0;
+}
+
+// Play (go/board.cc:1083-1179) of a LEGAL board move p for `player`; leaves the liberty table and
+// cls bits rebuilt.
 __device__ __forceinline__ void apply_move(WaveLds& L, const Geo& g, int lane, uint32_t lab[KCH],
                                            uint32_t lastp[KCH], Scalars& s, int p, int player) {
   const int c = pad_of(p);
@@ -287,12 +343,10 @@ __device__ __forceinline__ void apply_move(WaveLds& L, const Geo& g, int lane, u
   bool merged = false;
   GO_UNROLL
   for (int i = 0; i < 4; ++i) {
-    uint32_t col = n[i] >> 9;
-    int r = (int)(n[i] & 511);
-    own[i] = (col == (uint32_t)player) ? r : -1;
-    dead[i] = (col == opp && L.lib[r] == 1) ? r : -1;
-    own[i] = __builtin_amdgcn_readfirstlane(own[i]);
-    dead[i] = __builtin_amdgcn_readfirstlane(dead[i]);
+    const uint32_t col = col_of(n[i]);
+    const int r = (int)(n[i] & ROOT_MASK);
+    own[i] = __builtin_amdgcn_readfirstlane((col == (uint32_t)player) ? r : -1);
+    dead[i] = __builtin_amdgcn_readfirstlane((col == opp && cls_of(n[i]) == 1) ? r : -1);
     merged |= own[i] >= 0;
   }
   const uint32_t nv = ((uint32_t)player << 9) | (uint32_t)p;
@@ -300,20 +354,20 @@ __device__ __forceinline__ void apply_move(WaveLds& L, const Geo& g, int lane, u
   GO_UNROLL
   for (int k = 0; k < KCH; ++k) {
     uint32_t v = lab[k];
-    int r = (int)(v & 511);
-    uint32_t col = v >> 9;
-    bool mine = col == (uint32_t)player && (r == own[0] || r == own[1] || r == own[2] || r == own[3]);
-    bool cap = col == opp && (r == dead[0] || r == dead[1] || r == dead[2] || r == dead[3]);
+    const int r = (int)(v & ROOT_MASK);
+    const uint32_t col = col_of(v);
+    const bool mine = col == (uint32_t)player && (r == own[0] || r == own[1] || r == own[2] || r == own[3]);
+    const bool cap = col == opp && (r == dead[0] || r == dead[1] || r == dead[2] || r == dead[3]);
     if (mine) v = nv;
     if (cap) v = 0;
     if (g.p[k] == p) { v = nv; lastp[k] = (uint32_t)s.ply & 0xffffu; }  // board.cc:532,1157
-    unsigned long long m = __ballot(cap);
+    const unsigned long long m = __ballot(cap);
     if (m) { total_capture += popc64(m); capture_p = 64 * k + (int)__builtin_ctzll(m); }
     if (v != lab[k]) { L.lab[g.c[k]] = (uint16_t)v; lab[k] = v; }
   }
   if (player == S_BLACK) s.bcap += total_capture; else s.wcap += total_capture;  // board.cc:1132-1133
   WSYNC();
-  rebuild_lib(L, g, lab);
+  rebuild_lib(L, g, lane, lab);
   // simple ko, board.cc:1163-1171
   if (!merged && total_capture == 1 && L.lib[p] == 1) {
     s.ko = capture_p; s.kocolor = (int)opp; s.koage = 0;
@@ -336,28 +390,25 @@ __device__ __forceinline__ uint64_t policy_rand(uint64_t seed, uint64_t board_id
   return mix64(z + ply * 0x9E3779B97F4A7C15ull);
 }
 
-// cfg-2 policy: uniform over (legal AND NOT own true eye), pass if none.  Wave-uniform result.
-__device__ __forceinline__ int pick_random_move(const WaveLds& L, const Geo& g, int lane,
-                                                const uint32_t lab[KCH], const Scalars& s,
-                                                uint64_t seed, uint64_t board_id) {
-  bool legal[KCH], eye[KCH];
-  move_masks<true>(L, g, lab, s, s.next, legal, eye);
-  unsigned long long w[KCH];
+// cfg-2 policy: uniform over the candidate ballots (legal AND NOT own true eye), pass if none.
+// Wave-uniform result.
+__device__ __forceinline__ int pick_random_move(const Masks& m, int lane, const Scalars& s, uint64_t seed,
+                                                uint64_t board_id) {
   int n = 0;
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) { w[k] = __ballot(legal[k] && !eye[k]); n += popc64(w[k]); }
+  for (int k = 0; k < KCH; ++k) n += popc64(m.cand[k]);
   if (n == 0) return -1;
-  uint64_t u = policy_rand(seed, board_id, (uint64_t)s.game, (uint64_t)s.ply);
+  const uint64_t u = policy_rand(seed, board_id, (uint64_t)s.game, (uint64_t)s.ply);
   int idx = (int)(((u >> 32) * (uint64_t)n) >> 32);
   int chosen = -1;
   GO_UNROLL
   for (int k = 0; k < KCH; ++k) {
-    int cnt = popc64(w[k]);
+    const unsigned long long w = m.cand[k];
+    const int cnt = popc64(w);
     if (chosen < 0) {
       if (idx < cnt) {
-        int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(w[k] >> 32),
-                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)w[k], 0u));
-        unsigned long long hit = __ballot(((w[k] >> lane) & 1ull) && rank == idx);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(w >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)w, 0u));
+        const unsigned long long hit = __ballot(((w >> lane) & 1ull) && rank == idx);
         chosen = 64 * k + (int)__builtin_ctzll(hit);
       } else {
         idx -= cnt;
@@ -383,7 +434,7 @@ __device__ __forceinline__ int tromp_taylor(WaveLds& L, const Geo& g, int lane, 
       nbr4(L, g.c[k], n);
       GO_UNROLL
       for (int i = 0; i < 4; ++i) {
-        uint32_t col = n[i] >> 9;
+        const uint32_t col = col_of(n[i]);
         if (col == 1 || col == 2) f[k] |= col;
       }
       flag[g.c[k]] = (uint16_t)f[k];
@@ -395,8 +446,8 @@ __device__ __forceinline__ int tromp_taylor(WaveLds& L, const Geo& g, int lane, 
     GO_UNROLL
     for (int k = 0; k < KCH; ++k) {
       if (g.p[k] < NPTS && lab[k] == 0) {
-        int c = g.c[k];
-        uint32_t nf = f[k] | flag[c - PW] | flag[c - 1] | flag[c + PW] | flag[c + 1];
+        const int c = g.c[k];
+        const uint32_t nf = f[k] | flag[c - PW] | flag[c - 1] | flag[c + PW] | flag[c + 1];
         if (nf != f[k]) { f[k] = nf; flag[c] = (uint16_t)nf; changed = true; }
       }
       WSYNC();
@@ -406,8 +457,8 @@ __device__ __forceinline__ int tromp_taylor(WaveLds& L, const Geo& g, int lane, 
   int black = 0, white = 0;
   GO_UNROLL
   for (int k = 0; k < KCH; ++k) {
-    uint32_t col = lab[k] >> 9;
-    bool e = g.p[k] < NPTS && lab[k] == 0;
+    const uint32_t col = col_of(lab[k]);
+    const bool e = g.p[k] < NPTS && lab[k] == 0;
     black += popc64(__ballot(col == 1 || (e && f[k] == 1)));
     white += popc64(__ballot(col == 2 || (e && f[k] == 2)));
   }
@@ -415,18 +466,20 @@ __device__ __forceinline__ int tromp_taylor(WaveLds& L, const Geo& g, int lane, 
   return black - white;
 }
 
-// GetFastScore(board, RULE_CHINESE), go/board.cc:1560-1582: stones + true eyes per colour.
+// GetFastScore(board, RULE_CHINESE), go/board.cc:1560-1582: stones + true eyes per colour
+// (GetEyeColor tests white first, :1554-1558).
 __device__ __forceinline__ int fast_score_cn(const WaveLds& L, const Geo& g, const uint32_t lab[KCH],
                                              const Scalars& s) {
-  bool lg[KCH], eb[KCH], ew[KCH];
-  move_masks<true>(L, g, lab, s, S_BLACK, lg, eb);
-  move_masks<true>(L, g, lab, s, S_WHITE, lg, ew);
+  Masks m;
+  unsigned long long eb[KCH], ew[KCH];
+  move_masks(L, g, lab, s, S_BLACK, m, eb);
+  move_masks(L, g, lab, s, S_WHITE, m, ew);
   int sc = 0;
   GO_UNROLL
   for (int k = 0; k < KCH; ++k) {
-    uint32_t col = lab[k] >> 9;
-    sc += popc64(__ballot(col == 1 || (eb[k] && !ew[k])));
-    sc -= popc64(__ballot(col == 2 || ew[k]));
+    const uint32_t col = col_of(lab[k]);
+    sc += popc64(__ballot(col == 1)) + popc64(eb[k] & ~ew[k]);
+    sc -= popc64(__ballot(col == 2)) + popc64(ew[k]);
   }
   return sc;
 }
@@ -439,8 +492,8 @@ __device__ __forceinline__ int distance_maps(WaveLds& L, int lane, const uint32_
   unsigned long long wb[KCH + 1], ww[KCH + 1];
   GO_UNROLL
   for (int k = 0; k < KCH; ++k) {
-    wb[k] = __ballot((lab[k] >> 9) == 1);
-    ww[k] = __ballot((lab[k] >> 9) == 2);
+    wb[k] = __ballot(col_of(lab[k]) == 1);
+    ww[k] = __ballot(col_of(lab[k]) == 2);
   }
   wb[KCH] = 0; ww[KCH] = 0;
   int has = 0;
@@ -454,11 +507,11 @@ __device__ __forceinline__ int distance_maps(WaveLds& L, int lane, const uint32_
     const int bit = x * BS, w = bit >> 6, off = bit & 63;
     unsigned long long vb = wb[w] >> off, vw = ww[w] >> off;
     if (off > 64 - BS) { vb |= wb[w + 1] << (64 - off); vw |= ww[w + 1] << (64 - off); }
-    uint32_t m = (uint32_t)(white_lane ? vw : vb) & 0x7ffffu;
-    uint32_t lo = m & ((2u << y) - 1u);
-    uint32_t hi = m >> y;
-    int dl = lo ? y - (31 - __clz((int)lo)) : DIST_INF;
-    int dh = hi ? (int)__builtin_ctz(hi) : DIST_INF;
+    const uint32_t m = (uint32_t)(white_lane ? vw : vb) & 0x7ffffu;
+    const uint32_t lo = m & ((2u << y) - 1u);
+    const uint32_t hi = m >> y;
+    const int dl = lo ? y - (31 - __clz((int)lo)) : DIST_INF;
+    const int dh = hi ? (int)__builtin_ctz(hi) : DIST_INF;
     a[x] = min(dl, dh);
   }
   GO_UNROLL
@@ -493,14 +546,13 @@ __device__ __forceinline__ void write_features(WaveLds& L, const Geo& g, int lan
                                                const float* __restrict__ lut, float* __restrict__ out) {
   const int has = distance_maps(L, lane, lab);
   const int ko_p = (s.koage == 0 && s.ko >= 0) ? s.ko : -1;  // GetSimpleKoLocation, board.cc:337-344
-  // descriptor: colour(2) | libclass(2) | ko(1) | d_black(7) | d_white(7) | hist(11)
+  // descriptor: colour(2) | cls(2) | ko(1) | d_black(7) | d_white(7) | hist age(11)
   GO_UNROLL
   for (int k = 0; k < KCH; ++k) {
     if (g.p[k] < NPTS) {
-      uint32_t v = lab[k], col = v >> 9, d = col;
-      if (col) {
-        uint32_t lib = L.lib[v & 511];
-        d |= (lib == 1 ? 0u : (lib == 2 ? 1u : 2u)) << 2;  // GetLibertyMap3binary :83-99
+      const uint32_t v = lab[k];
+      uint32_t d = typ_of(v);  // colour | cls<<2 ; cls 1,2,3 <-> GetLibertyMap3binary :83-99
+      if (v) {
         int age = s.ply - (int)lastp[k];
         age = age < 0 ? 0 : (age > HIST_LUT_N - 1 ? HIST_LUT_N - 1 : age);
         d |= (uint32_t)age << 19;
@@ -519,7 +571,7 @@ __device__ __forceinline__ void write_features(WaveLds& L, const Geo& g, int lan
   float h[KCH];
   GO_UNROLL
   for (int k = 0; k < KCH; ++k) {
-    int q = g.p[k];
+    const int q = g.p[k];
     d[k] = 0; h[k] = 0.f;
     if (q < NPTS) {
       d[k] = L.desc[aug ? d4_source(aug, q) : q];
@@ -533,12 +585,12 @@ __device__ __forceinline__ void write_features(WaveLds& L, const Geo& g, int lan
       const uint32_t col = d[k] & 3u, cls = (d[k] >> 2) & 3u;
       const bool mine = col == our, theirs = col == opp;
       float* o = out + q;
-      o[0 * NPTS] = (mine && cls == 0) ? 1.f : 0.f;
-      o[1 * NPTS] = (mine && cls == 1) ? 1.f : 0.f;
-      o[2 * NPTS] = (mine && cls == 2) ? 1.f : 0.f;
-      o[3 * NPTS] = (theirs && cls == 0) ? 1.f : 0.f;
-      o[4 * NPTS] = (theirs && cls == 1) ? 1.f : 0.f;
-      o[5 * NPTS] = (theirs && cls == 2) ? 1.f : 0.f;
+      o[0 * NPTS] = (mine && cls == 1) ? 1.f : 0.f;
+      o[1 * NPTS] = (mine && cls == 2) ? 1.f : 0.f;
+      o[2 * NPTS] = (mine && cls != 1 && cls != 2) ? 1.f : 0.f;  // literally "else", :93
+      o[3 * NPTS] = (theirs && cls == 1) ? 1.f : 0.f;
+      o[4 * NPTS] = (theirs && cls == 2) ? 1.f : 0.f;
+      o[5 * NPTS] = (theirs && cls != 1 && cls != 2) ? 1.f : 0.f;
       o[6 * NPTS] = (d[k] & 16u) ? 1.f : 0.f;
       o[7 * NPTS] = mine ? 1.f : 0.f;
       o[8 * NPTS] = theirs ? 1.f : 0.f;
@@ -555,13 +607,10 @@ __device__ __forceinline__ void write_features(WaveLds& L, const Geo& g, int lan
   }
 }
 
-__device__ __forceinline__ void write_legal(const WaveLds& L, const Geo& g, const uint32_t lab[KCH],
-                                            const Scalars& s, uint8_t* __restrict__ out) {
-  bool legal[KCH], eye[KCH];
-  move_masks<false>(L, g, lab, s, s.next, legal, eye);
+__device__ __forceinline__ void write_legal(const Geo& g, int lane, const Masks& m, uint8_t* __restrict__ out) {
   GO_UNROLL
   for (int k = 0; k < KCH; ++k)
-    if (g.p[k] < NPTS) out[g.p[k]] = legal[k] ? 1 : 0;
+    if (g.p[k] < NPTS) out[g.p[k]] = (uint8_t)((m.legal[k] >> lane) & 1ull);
 }
 
 }  // namespace goenv

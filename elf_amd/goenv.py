@@ -16,7 +16,7 @@ NUM_POINTS = 361
 NUM_PLANES = 25
 FEAT_FLOATS = NUM_PLANES * NUM_POINTS
 NUM_STATS = 16
-REC_BYTES = 2272
+REC_BYTES = 1632
 PASS = -1
 RESIGN = -2
 

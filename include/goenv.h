@@ -43,7 +43,7 @@ extern "C" {
 #define GOENV_FEAT_FLOATS (25 * 361)              /* 9025 floats / board   */
 #define GOENV_NUM_SCALARS 16
 #define GOENV_NUM_STATS 16
-#define GOENV_REC_BYTES 2272                      /* packed board record   */
+#define GOENV_REC_BYTES 1632                      /* packed board record   */
 
 #define GOENV_PASS (-1)
 #define GOENV_RESIGN (-2)

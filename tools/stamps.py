@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Diagnostic (never timed as a result): where one fused random ply spends its wave cycles.
+Needs elf_amd/libgoenv_diag.so = goenv.hip built with -DGOENV_STAMPS.  Prints the median over
+boards of each phase's share.  Usage: tools/stamps.py [boards] [warm plies]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from elf_amd import goenv  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+lib = goenv.load_library(os.path.join(ROOT, "elf_amd", "libgoenv_diag.so"))
+lib.goenv_diag_ply.restype = C.c_int
+lib.goenv_diag_ply.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+env = goenv.GoEnv(B, seed=1)
+feat, legal = env.new(torch.float32, 25, 19, 19), env.new(torch.uint8, 361)
+stamps = torch.zeros((B, 16), dtype=torch.int64, device=env.device)
+for _ in range(warm):
+    env.ply(goenv.F_RANDOM_POLICY | goenv.F_AUTO_RESTART, feat_out=feat, legal_out=legal)
+names = {1: "load_board", 2: "pick_move", 3: "apply+rebuild", 4: "move_masks", 5: "store_state", 6: "legal_out", 7: "features"}
+acc = None
+for rep in range(20):
+    lib.goenv_diag_ply(env._h, goenv.F_AUTO_RESTART, feat.data_ptr(), legal.data_ptr(), stamps.data_ptr(), None)
+    torch.cuda.synchronize()
+    s = stamps.cpu()
+    idx = [0, 1, 2, 3, 4, 5, 6, 7]
+    d = torch.stack([s[:, idx[i + 1]] - s[:, idx[i]] for i in range(len(idx) - 1)], 1).double()
+    acc = d if acc is None else acc + d
+acc /= 20
+med = acc.median(0).values
+tot = (s[:, 7] - s[:, 0]).double()
+print("boards", B, "median wave cycles (s_memtime ticks @100MHz? see guide) per phase:")
+for i, k in enumerate([1, 2, 3, 4, 5, 6, 7]):
+    print("  %-14s %9.0f  (%.1f%%)" % (names[k], med[i].item(), 100 * med[i].item() / med.sum().item()))
+print("  total median %.0f  max %.0f" % (tot.median().item(), tot.max().item()))
+print("  grid span (last end - first start): %d" % int(s[:, 7].max() - s[:, 0].min()))
