@@ -21,7 +21,11 @@ using namespace goenv;
 
 struct PlyParams {
   BoardRec* state;
-  int n;
+  int n;            // rows of this launch
+  int n_total;      // boards in the context
+  const int32_t* idx;  // board of row b = idx ? idx[b] : first + b
+  int first;
+  goenv_sample_out meta;
   uint32_t flags;
   const int64_t* actions;
   const int32_t* aug;
@@ -71,15 +75,50 @@ __device__ __forceinline__ void account_game(unsigned long long* stats, int lane
   }
 }
 
+// Board of launch row b (selection by index list or by contiguous range); -1 if out of range.
+__device__ __forceinline__ int board_of(const int32_t* idx, int first, int n_total, int b) {
+  const int board = idx ? idx[b] : first + b;
+  return (board >= 0 && board < n_total) ? board : -1;
+}
+
+// A game restarts in place: empty board, next game of this slot, seq 0 (AICommT::Restart ->
+// SeqInfo::NewEpisode, elf/ai_comm.h:91-95, elf/common.h:18).
+__device__ __forceinline__ void restart_in_place(WaveLds& L, const Geo& g, int lane, uint32_t lab[KCH],
+                                                 uint32_t lastp[KCH], Scalars& s, Masks& m) {
+  clear_board_lds(L, g, lane, lab, lastp);
+  const int game = s.game + 1;
+  clear_scalars(s);
+  s.game = game;
+  full_masks(m);
+}
+
+// One sample's sequencing record (GameState::Prepare, go/go_game_specific.h:91-98 +
+// SeqInfo, elf/common.h:11-19): written for row b, then the board's seq advances.
+__device__ __forceinline__ void emit_sample_meta(const goenv_sample_out& o, int b, int board, int lane,
+                                                 Scalars& s, int aug) {
+  if (lane == 0) {
+    if (o.id) o.id[b] = board;
+    if (o.seq) o.seq[b] = s.seq;
+    if (o.game_counter) o.game_counter[b] = s.game;
+    if (o.last_terminal) o.last_terminal[b] = (int8_t)((s.seq == 0 && s.game > 0) ? 1 : 0);
+    if (o.move_idx) o.move_idx[b] = s.ply;  // gs.move_idx = state.GetPly(), go/go_ai.h:82
+    if (o.winner) o.winner[b] = 0;
+    if (o.aug_code) o.aug_code[b] = aug;
+    if (o.game_record_idx) o.game_record_idx[b] = -1;
+  }
+  s.seq += 1;
+}
+
 // One ply for one board held in LDS/registers.  Returns the action applied (-1 pass) or
 // -4 if the external action was illegal (state untouched).  On return `m` holds the masks of
 // the new side to move.
 template <bool RANDOM>
 __device__ __forceinline__ int ply_body(WaveLds& L, const Geo& g, int lane, uint32_t lab[KCH],
-                                        uint32_t lastp[KCH], Scalars& s, Masks& m, const PlyParams& P, int b) {
+                                        uint32_t lastp[KCH], Scalars& s, Masks& m, const PlyParams& P, int b,
+                                        int board) {
   int a;
   if (RANDOM) {
-    a = pick_random_move(m, lane, s, P.seed, (uint64_t)(P.id_base + b));
+    a = pick_random_move(m, lane, s, P.seed, (uint64_t)(P.id_base + board));
     a = __builtin_amdgcn_readfirstlane(a);
     STAMP(2);
   } else {
@@ -114,10 +153,15 @@ __global__ __launch_bounds__(64) void k_ply(PlyParams P) {
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
   if (b >= P.n) return;
+  const int board = board_of(P.idx, P.first, P.n_total, b);
+  if (board < 0) {
+    if (lane == 0 && P.status) P.status[b] = -2;
+    return;
+  }
   STAMP(0);
   Geo g;
   geo_init(g, lane);
-  BoardRec* rec = P.state + b;
+  BoardRec* rec = P.state + board;
   Scalars s;
   load_scalars(rec, s);
   uint32_t lab[KCH], lastp[KCH];
@@ -130,25 +174,33 @@ __global__ __launch_bounds__(64) void k_ply(PlyParams P) {
   if (s.done) {
     if (P.flags & GOENV_F_AUTO_RESTART) {
       if (!s.counted) account_game(P.stats, lane, s, tromp_taylor(L, g, lane, lab), P.komi);
-      clear_board_lds(L, g, lane, lab, lastp);
-      const int game = s.game + 1;
-      clear_scalars(s);
-      s.game = game;
-      full_masks(m);
+      restart_in_place(L, g, lane, lab, lastp, s, m);
     } else if (P.flags & GOENV_F_SKIP_DONE) {
       skip = true;
     }
   }
-  int a = -3;
+  int a = -3, status = -1;
   if (!skip) {
-    a = ply_body<RANDOM>(L, g, lane, lab, lastp, s, m, P, b);
+    a = ply_body<RANDOM>(L, g, lane, lab, lastp, s, m, P, b, board);
+    status = (a == -4) ? 0 : 1;
+    if (a == -4 && (P.flags & GOENV_F_RESET_ILLEGAL)) {
+      // "No valid move ..., restarting the game", go/game.cc:81-90
+      restart_in_place(L, g, lane, lab, lastp, s, m);
+    } else if (a != -4 && s.done && (P.flags & GOENV_F_RESTART_AFTER_END)) {
+      account_game(P.stats, lane, s, tromp_taylor(L, g, lane, lab), P.komi);
+      restart_in_place(L, g, lane, lab, lastp, s, m);
+      status = 2;
+    }
     STAMP(4);
-    if (a != -4) store_board(rec, g, lane, lab, lastp, m, s);
+    const int aug = P.aug ? (P.aug[b] & 7) : 0;
+    if (P.flags & GOENV_F_COLLECT) emit_sample_meta(P.meta, b, board, lane, s, aug);
+    if (a != -4 || (P.flags & (GOENV_F_RESET_ILLEGAL | GOENV_F_COLLECT)))
+      store_board(rec, g, lane, lab, lastp, m, s);
   }
   STAMP(5);
   if (lane == 0) {
     if (P.actions_out) P.actions_out[b] = a;
-    if (P.status) P.status[b] = (a == -4) ? 0 : (a == -3 ? -1 : 1);
+    if (P.status) P.status[b] = status;
   }
   if (skip) return;
   if (P.legal) write_legal(g, lane, m, P.legal + (size_t)b * NPTS);
@@ -160,27 +212,99 @@ __global__ __launch_bounds__(64) void k_ply(PlyParams P) {
   STAMP(7);
 }
 
-__global__ __launch_bounds__(64) void k_features(const BoardRec* state, int n, const int32_t* aug_codes,
-                                                 const float* lut, float* feat, uint8_t* legal) {
+// Planes (+ mask, + sequencing record) of the CURRENT positions of the selected boards.
+__global__ __launch_bounds__(64) void k_features(BoardRec* state, int n_total, const int32_t* idx, int first,
+                                                 int n, const int32_t* aug_codes, const float* lut, float* feat,
+                                                 uint8_t* legal, goenv_sample_out meta, int collect) {
   __shared__ WaveLds L;
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= n) return;
+  const int board = board_of(idx, first, n_total, b);
+  if (board < 0) return;
   Geo g;
   geo_init(g, lane);
-  const BoardRec* rec = state + b;
+  BoardRec* rec = state + board;
   Scalars s;
   load_scalars(rec, s);
   uint32_t lab[KCH], lastp[KCH];
   load_board(rec, L, g, lane, lab, lastp);
+  const int aug = aug_codes ? (aug_codes[b] & 7) : 0;
+  if (collect) {
+    emit_sample_meta(meta, b, board, lane, s, aug);
+    if (lane == 0) rec->sc[SC_SEQ] = s.seq;
+  }
   if (legal) {
     Masks m;
     load_masks(rec, m);
     write_legal(g, lane, m, legal + (size_t)b * NPTS);
   }
-  if (feat) {
-    const int aug = aug_codes ? (aug_codes[b] & 7) : 0;
-    write_features(L, g, lane, lab, lastp, s, aug, lut, feat + (size_t)b * GOENV_FEAT_FLOATS);
+  if (feat) write_features(L, g, lane, lab, lastp, s, aug, lut, feat + (size_t)b * GOENV_FEAT_FLOATS);
+}
+
+// Move selection from a policy head: sample p proportional to pi[p] over the LEGAL points, in exact
+// integer arithmetic (weights floor(pi * 2^24)), keyed by the counter RNG; all-zero weights fall
+// back to the cfg-2 random policy.  pi is indexed in the augmented frame of aug_codes[b].
+__global__ __launch_bounds__(64) void k_sample_policy(const BoardRec* state, int n_total, const int32_t* idx,
+                                                      int first, int n, const float* pi, const int32_t* aug_codes,
+                                                      int64_t* actions_out, uint64_t seed, int64_t id_base) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= n) return;
+  const int board = board_of(idx, first, n_total, b);
+  if (board < 0) {
+    if (lane == 0) actions_out[b] = -1;
+    return;
   }
+  const BoardRec* rec = state + board;
+  Scalars s;
+  load_scalars(rec, s);
+  Masks m;
+  load_masks(rec, m);
+  const int aug = aug_codes ? (aug_codes[b] & 7) : 0;
+  const float* row = pi + (size_t)b * NPTS;
+  uint32_t pre[KCH], sum[KCH];
+  unsigned long long total = 0;
+  GO_UNROLL
+  for (int k = 0; k < KCH; ++k) {
+    const int p = lane + 64 * k;
+    uint32_t w = 0;
+    if (p < NPTS && ((m.legal[k] >> lane) & 1ull)) {
+      const float f = row[aug ? d4_dest(aug, p) : p];
+      if (f > 0.f) {
+        const float sc = f * 16777216.0f;
+        w = sc >= 16777216.0f ? 16777216u : (uint32_t)sc;
+      }
+    }
+    uint32_t v = w;
+    GO_UNROLL
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(v, d);
+      if (lane >= d) v += t;
+    }
+    pre[k] = v;
+    sum[k] = __shfl(v, 63);
+    total += sum[k];
+  }
+  int a;
+  if (total == 0) {
+    a = pick_random_move(m, lane, s, seed, (uint64_t)(id_base + board));
+  } else {
+    const uint64_t u = policy_rand(seed ^ 0xA5A5A5A55A5A5A5Aull, (uint64_t)(id_base + board), (uint64_t)s.game,
+                                   (uint64_t)s.ply);
+    unsigned long long r = u % total;
+    a = -1;
+    GO_UNROLL
+    for (int k = 0; k < KCH; ++k) {
+      if (a < 0) {
+        if (r < sum[k]) {
+          const unsigned long long hit = __ballot((unsigned long long)pre[k] > r);
+          a = 64 * k + (int)__builtin_ctzll(hit);
+        } else {
+          r -= sum[k];
+        }
+      }
+    }
+  }
+  if (lane == 0) actions_out[b] = a;
 }
 
 __global__ __launch_bounds__(64) void k_score(const BoardRec* state, int n, float* tt, float* fast) {
@@ -286,7 +410,7 @@ __global__ __launch_bounds__(64) void k_get_state(const BoardRec* state, int n, 
   }
   if (scalars && lane < 16) {
     int v = rec->sc[lane];
-    if (lane >= SC_COUNTED) v = 0;
+    if (lane == SC_COUNTED || lane == SC_R15) v = 0;
     scalars[(size_t)b * 16 + lane] = v;
   }
 }
@@ -339,7 +463,7 @@ __global__ __launch_bounds__(64) void k_set_state(BoardRec* state, int n, const 
   s.ply = sc[0]; s.next = sc[1]; s.bcap = sc[2]; s.wcap = sc[3];
   s.l1 = sc[4]; s.l2 = sc[5]; s.l3 = sc[6]; s.l4 = sc[7];
   s.koage = sc[8] & 0xffff; s.ko = sc[9]; s.kocolor = sc[10];
-  s.done = sc[11]; s.game = sc[12]; s.counted = 0;
+  s.done = sc[11]; s.game = sc[12]; s.counted = 0; s.seq = sc[14];
   Masks mk;
   unsigned long long eye[KCH];
   move_masks(L, g, lab, s, s.next, mk, eye);
@@ -379,7 +503,7 @@ __global__ __launch_bounds__(64) void k_playout(PlyParams P, int16_t* moves, int
   int cnt = 0;
   // exit condition every wave reaches: done flag, or the hard bound on iterations
   for (int it = 0; it < 4096 && !s.done; ++it) {
-    int a = ply_body<true>(L, g, lane, lab, lastp, s, m, P, b);
+    int a = ply_body<true>(L, g, lane, lab, lastp, s, m, P, b, b);
     if (moves && cnt < max_record && lane == 0) moves[(size_t)b * max_record + cnt] = (int16_t)a;
     ++cnt;
   }
@@ -515,23 +639,44 @@ int goenv_set_state(goenv_ctx* c, const uint8_t* color, const uint16_t* last_pla
 static PlyParams make_params(goenv_ctx* c, uint32_t flags, const int64_t* actions, const int32_t* aug, float* feat,
                              uint8_t* legal, int32_t* actions_out, int32_t* status) {
   PlyParams P;
-  P.state = c->state; P.n = c->n; P.flags = flags; P.actions = actions; P.aug = aug; P.feat = feat;
+  memset(&P, 0, sizeof(P));
+  P.state = c->state; P.n = c->n; P.n_total = c->n; P.idx = nullptr; P.first = 0;
+  P.flags = flags; P.actions = actions; P.aug = aug; P.feat = feat;
   P.legal = legal; P.actions_out = actions_out; P.status = status; P.stats = c->stats; P.lut = c->lut;
   P.seed = c->seed; P.id_base = c->id_base; P.komi = c->komi; P.max_ply = c->max_ply;
   P.stamps = nullptr;
   return P;
 }
 
+static int check_sel(goenv_ctx* c, const int32_t* idx, int first, int count, const char* who) {
+  if (!c) { fail(who); g_err += ": ctx is NULL"; return -1; }
+  if (count < 0 || count > c->n) { fail(who); g_err += ": count out of range"; return -1; }
+  if (!idx && (first < 0 || first + count > c->n)) { fail(who); g_err += ": board range out of bounds"; return -1; }
+  return 0;
+}
+
+int goenv_ply_sel(goenv_ctx* c, const int32_t* idx, int first, int count, uint32_t flags, const int64_t* actions,
+                  const int32_t* aug_codes, float* feat_out, uint8_t* legal_out, const goenv_sample_out* meta,
+                  int32_t* actions_out, int32_t* status_out, void* stream) {
+  if (check_sel(c, idx, first, count, "goenv_ply_sel")) return -1;
+  const bool random = flags & GOENV_F_RANDOM_POLICY;
+  if (!random && !actions) return fail("goenv_ply: actions required unless GOENV_F_RANDOM_POLICY is set");
+  if ((flags & GOENV_F_COLLECT) && !meta) return fail("goenv_ply: GOENV_F_COLLECT needs a goenv_sample_out");
+  if (count == 0) return 0;
+  PlyParams P = make_params(c, flags, actions, aug_codes, feat_out, legal_out, actions_out, status_out);
+  P.n = count; P.idx = idx; P.first = first;
+  if (meta) P.meta = *meta;
+  if (random) hipLaunchKernelGGL(k_ply<true>, dim3(count), dim3(64), 0, S(stream), P);
+  else hipLaunchKernelGGL(k_ply<false>, dim3(count), dim3(64), 0, S(stream), P);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int goenv_ply(goenv_ctx* c, uint32_t flags, const int64_t* actions, const int32_t* aug_codes, float* feat_out,
               uint8_t* legal_out, int32_t* actions_out, int32_t* status_out, void* stream) {
   if (!c) return fail("goenv_ply: ctx is NULL");
-  const bool random = flags & GOENV_F_RANDOM_POLICY;
-  if (!random && !actions) return fail("goenv_ply: actions required unless GOENV_F_RANDOM_POLICY is set");
-  PlyParams P = make_params(c, flags, actions, aug_codes, feat_out, legal_out, actions_out, status_out);
-  if (random) hipLaunchKernelGGL(k_ply<true>, dim3(c->n), dim3(64), 0, S(stream), P);
-  else hipLaunchKernelGGL(k_ply<false>, dim3(c->n), dim3(64), 0, S(stream), P);
-  HIPCHK(hipGetLastError());
-  return 0;
+  return goenv_ply_sel(c, nullptr, 0, c->n, flags & ~GOENV_F_COLLECT, actions, aug_codes, feat_out, legal_out,
+                       nullptr, actions_out, status_out, stream);
 }
 
 #ifdef GOENV_STAMPS
@@ -551,12 +696,65 @@ int goenv_step(goenv_ctx* c, const int64_t* actions, uint8_t* legal_out, int32_t
   return goenv_ply(c, 0u, actions, nullptr, nullptr, legal_out, nullptr, status_out, stream);
 }
 
+int goenv_collect_sel(goenv_ctx* c, const int32_t* idx, int first, int count, const int32_t* aug_codes,
+                      float* feat_out, uint8_t* legal_out, const goenv_sample_out* meta, void* stream) {
+  if (check_sel(c, idx, first, count, "goenv_collect_sel")) return -1;
+  if (count == 0) return 0;
+  goenv_sample_out m;
+  memset(&m, 0, sizeof(m));
+  if (meta) m = *meta;
+  hipLaunchKernelGGL(k_features, dim3(count), dim3(64), 0, S(stream), c->state, c->n, idx, first, count, aug_codes,
+                     c->lut, feat_out, legal_out, m, meta ? 1 : 0);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int goenv_features(goenv_ctx* c, const int32_t* aug_codes, float* feat_out, uint8_t* legal_out, void* stream) {
   if (!c) return fail("goenv_features: ctx is NULL");
   if (!feat_out && !legal_out) return fail("goenv_features: no output buffer");
-  hipLaunchKernelGGL(k_features, dim3(c->n), dim3(64), 0, S(stream), c->state, c->n, aug_codes, c->lut, feat_out,
-                     legal_out);
+  return goenv_collect_sel(c, nullptr, 0, c->n, aug_codes, feat_out, legal_out, nullptr, stream);
+}
+
+int goenv_sample_policy(goenv_ctx* c, const int32_t* idx, int first, int count, const float* pi,
+                        const int32_t* aug_codes, int64_t* actions_out, void* stream) {
+  if (check_sel(c, idx, first, count, "goenv_sample_policy")) return -1;
+  if (!pi || !actions_out) return fail("goenv_sample_policy: pi and actions_out are required");
+  if (count == 0) return 0;
+  hipLaunchKernelGGL(k_sample_policy, dim3(count), dim3(64), 0, S(stream), c->state, c->n, idx, first, count, pi,
+                     aug_codes, actions_out, c->seed, c->id_base);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int goenv_pointer_is_device(const void* p) {
+  if (!p) return 0;
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();  // plain malloc memory: not registered with HIP
+    return 0;
+  }
+  return attr.type == hipMemoryTypeDevice ? 1 : 0;
+}
+
+int goenv_copy(void* dst, const void* src, size_t bytes, void* stream) {
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, S(stream)));
+  return 0;
+}
+
+int goenv_sync(void* stream) {
+  HIPCHK(hipStreamSynchronize(S(stream)));
+  return 0;
+}
+
+int goenv_device_alloc(goenv_ctx* c, size_t bytes, void** out) {
+  if (!c || !out) return fail("goenv_device_alloc: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMalloc(out, bytes ? bytes : 1));
+  return 0;
+}
+
+int goenv_device_free(void* p) {
+  if (p) HIPCHK(hipFree(p));
   return 0;
 }
 

@@ -49,7 +49,7 @@ constexpr int DIST_INF = 64;
 
 // scalar slots inside the record (same order as the canonical view, include/goenv.h)
 enum { SC_PLY = 0, SC_NEXT, SC_BCAP, SC_WCAP, SC_L1, SC_L2, SC_L3, SC_L4, SC_KOAGE, SC_KO,
-       SC_KOCOLOR, SC_DONE, SC_GAME, SC_COUNTED, SC_R14, SC_R15 };
+       SC_KOCOLOR, SC_DONE, SC_GAME, SC_COUNTED, SC_SEQ, SC_R15 };
 
 // Packed per-board record in HBM: 1632 B, 16-B aligned, one contiguous read per wave.
 struct __attribute__((aligned(16))) BoardRec {
@@ -70,7 +70,7 @@ struct WaveLds {
 };
 
 struct Scalars {
-  int ply, next, bcap, wcap, l1, l2, l3, l4, koage, ko, kocolor, done, game, counted;
+  int ply, next, bcap, wcap, l1, l2, l3, l4, koage, ko, kocolor, done, game, counted, seq;
 };
 
 struct Geo {
@@ -111,7 +111,7 @@ __device__ __forceinline__ void load_scalars(const BoardRec* rec, Scalars& s) {
   s.ply = sc[SC_PLY]; s.next = sc[SC_NEXT]; s.bcap = sc[SC_BCAP]; s.wcap = sc[SC_WCAP];
   s.l1 = sc[SC_L1]; s.l2 = sc[SC_L2]; s.l3 = sc[SC_L3]; s.l4 = sc[SC_L4];
   s.koage = sc[SC_KOAGE]; s.ko = sc[SC_KO]; s.kocolor = sc[SC_KOCOLOR];
-  s.done = sc[SC_DONE]; s.game = sc[SC_GAME]; s.counted = sc[SC_COUNTED];
+  s.done = sc[SC_DONE]; s.game = sc[SC_GAME]; s.counted = sc[SC_COUNTED]; s.seq = sc[SC_SEQ];
 }
 
 __device__ __forceinline__ void store_scalars(BoardRec* rec, const Scalars& s, int lane) {
@@ -125,6 +125,7 @@ __device__ __forceinline__ void store_scalars(BoardRec* rec, const Scalars& s, i
     case SC_KOAGE: v = s.koage; break;   case SC_KO: v = s.ko; break;
     case SC_KOCOLOR: v = s.kocolor; break; case SC_DONE: v = s.done; break;
     case SC_GAME: v = s.game; break;     case SC_COUNTED: v = s.counted; break;
+    case SC_SEQ: v = s.seq; break;
     default: v = 0;
   }
   if (lane < 16) rec->sc[lane] = v;
@@ -134,7 +135,7 @@ __device__ __forceinline__ void store_scalars(BoardRec* rec, const Scalars& s, i
 __device__ __forceinline__ void clear_scalars(Scalars& s) {
   s.ply = 1; s.next = S_BLACK; s.bcap = 0; s.wcap = 0;
   s.l1 = s.l2 = s.l3 = s.l4 = -1;
-  s.koage = 0; s.ko = -1; s.kocolor = 0; s.done = 0; s.counted = 0;
+  s.koage = 0; s.ko = -1; s.kocolor = 0; s.done = 0; s.counted = 0; s.seq = 0;
 }
 
 __device__ __forceinline__ void fill_rim(WaveLds& L, int lane) {
@@ -527,84 +528,120 @@ __device__ __forceinline__ int distance_maps(WaveLds& L, int lane, const uint32_
   return has;
 }
 
-// BoardFeature::Transform inverse (go/board_feature.h:50-60): source point of output index q.
-__device__ __forceinline__ int d4_source(int code, int q) {
-  int a = q / BS, b = q - a * BS;
-  if ((code >> 2) == 1) { int t = a; a = b; b = t; }
-  int rot = code & 3, x, y;
-  if (rot == 1) { x = BS - 1 - b; y = a; }
-  else if (rot == 2) { x = BS - 1 - a; y = BS - 1 - b; }
-  else if (rot == 3) { x = b; y = BS - 1 - a; }
-  else { x = a; y = b; }
-  return x * BS + y;
+// BoardFeature::Transform (go/board_feature.h:38-48): output index of point p under a D4 code.
+__device__ __forceinline__ int d4_dest(int code, int p) {
+  const int x = p / BS, y = p - x * BS;
+  const int rot = code & 3;
+  int ox, oy;
+  if (rot == 1) { ox = y; oy = BS - 1 - x; }
+  else if (rot == 2) { ox = BS - 1 - x; oy = BS - 1 - y; }
+  else if (rot == 3) { ox = BS - 1 - y; oy = x; }
+  else { ox = x; oy = y; }
+  if ((code >> 2) == 1) { const int t = ox; ox = oy; oy = t; }
+  return ox * BS + oy;
 }
 
-// BoardFeature::Extract (go/board_feature.cc:175-195): 25 planes x 361 floats, written
-// lane-contiguously.  `lut` = host-built (float)exp(-d/10.0) table (board_feature.cc:141).
+// 4 floats with only 4-byte alignment: planes start every 1444 B and boards every 36100 B, so
+// 16-B alignment is not available; gfx950 takes dwordx4 global stores at dword alignment at full
+// rate (tools/store_bench.hip).
+struct __attribute__((packed, aligned(4))) float4u { float x, y, z, w; };
+
+__device__ __forceinline__ void zero_range(float* __restrict__ o, int count, int lane) {
+  const float4u z = {0.f, 0.f, 0.f, 0.f};
+  const int body = count & ~3;
+  for (int i = 4 * lane; i < body; i += 256) *reinterpret_cast<float4u*>(o + i) = z;
+  if (lane < count - body) o[body + lane] = 0.f;
+}
+
+// BoardFeature::Extract (go/board_feature.cc:175-195): 25 planes x 361 floats.
+// Store shape: plane-major, each plane as two dwordx4 wave-stores (lane l: q = 4l..4l+3, then
+// q = 256+4l..; lane 26 covers 357..360, re-writing 3 floats with the same values), so a board's
+// 36,100 B leave the wave as ascending contiguous runs -- 45 store instructions instead of 150
+// dword stores, and 1.6x the HBM rate of point-major dword stores at 65,536 boards.
+// `lut` = host-built (float)exp(-d/10.0) table (board_feature.cc:141).
 __device__ __forceinline__ void write_features(WaveLds& L, const Geo& g, int lane, const uint32_t lab[KCH],
                                                const uint32_t lastp[KCH], const Scalars& s, int aug,
                                                const float* __restrict__ lut, float* __restrict__ out) {
+  // history values first: their global-load latency hides under the distance transform
+  float hv[KCH];
+  GO_UNROLL
+  for (int k = 0; k < KCH; ++k) {
+    hv[k] = 0.f;
+    if (g.p[k] < NPTS && lab[k]) {
+      int age = s.ply - (int)lastp[k];
+      age = age < 0 ? 0 : (age > HIST_LUT_N - 1 ? HIST_LUT_N - 1 : age);
+      hv[k] = lut[age];
+    }
+  }
   const int has = distance_maps(L, lane, lab);
   const int ko_p = (s.koage == 0 && s.ko >= 0) ? s.ko : -1;  // GetSimpleKoLocation, board.cc:337-344
-  // descriptor: colour(2) | cls(2) | ko(1) | d_black(7) | d_white(7) | hist age(11)
+  // per-point descriptor, scattered to its OUTPUT index (D4 applied here):
+  //   colour(2) | cls(2) | ko(1) | d_black(7) | d_white(7);  history value in a parallel table
+  float* hist = reinterpret_cast<float*>(L.lib);  // the liberty table is dead from here on
   GO_UNROLL
   for (int k = 0; k < KCH; ++k) {
     if (g.p[k] < NPTS) {
-      const uint32_t v = lab[k];
-      uint32_t d = typ_of(v);  // colour | cls<<2 ; cls 1,2,3 <-> GetLibertyMap3binary :83-99
-      if (v) {
-        int age = s.ply - (int)lastp[k];
-        age = age < 0 ? 0 : (age > HIST_LUT_N - 1 ? HIST_LUT_N - 1 : age);
-        d |= (uint32_t)age << 19;
-      }
+      uint32_t d = typ_of(lab[k]);  // cls 1,2,3 <-> GetLibertyMap3binary :83-99
       if (g.p[k] == ko_p) d |= 16u;
       d |= (uint32_t)L.dist[0][g.p[k]] << 5;
       d |= (uint32_t)L.dist[1][g.p[k]] << 12;
-      L.desc[g.p[k]] = d;
+      const int q = aug ? d4_dest(aug, g.p[k]) : g.p[k];
+      L.desc[q] = d;
+      hist[q] = hv[k];
     }
   }
   WSYNC();
   const uint32_t our = (uint32_t)s.next, opp = 3u - our;
   const bool has_our = (has >> (our - 1)) & 1, has_opp = (has >> (opp - 1)) & 1;
   const int sh_our = our == 1 ? 5 : 12, sh_opp = our == 1 ? 12 : 5;
-  uint32_t d[KCH];
-  float h[KCH];
+  const int qa = 4 * lane;
+  const int qb = lane < 26 ? 256 + 4 * lane : NPTS - 4;
+  uint32_t d[8];
+  float h[8];
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
-    const int q = g.p[k];
-    d[k] = 0; h[k] = 0.f;
-    if (q < NPTS) {
-      d[k] = L.desc[aug ? d4_source(aug, q) : q];
-      if (d[k] & 3u) h[k] = lut[d[k] >> 19];
-    }
+  for (int i = 0; i < 4; ++i) {
+    d[i] = L.desc[qa + i];
+    h[i] = hist[qa + i];
+    d[4 + i] = L.desc[qb + i];
+    h[4 + i] = hist[qb + i];
   }
-  GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
-    const int q = g.p[k];
-    if (q < NPTS) {
-      const uint32_t col = d[k] & 3u, cls = (d[k] >> 2) & 3u;
-      const bool mine = col == our, theirs = col == opp;
-      float* o = out + q;
-      o[0 * NPTS] = (mine && cls == 1) ? 1.f : 0.f;
-      o[1 * NPTS] = (mine && cls == 2) ? 1.f : 0.f;
-      o[2 * NPTS] = (mine && cls != 1 && cls != 2) ? 1.f : 0.f;  // literally "else", :93
-      o[3 * NPTS] = (theirs && cls == 1) ? 1.f : 0.f;
-      o[4 * NPTS] = (theirs && cls == 2) ? 1.f : 0.f;
-      o[5 * NPTS] = (theirs && cls != 1 && cls != 2) ? 1.f : 0.f;
-      o[6 * NPTS] = (d[k] & 16u) ? 1.f : 0.f;
-      o[7 * NPTS] = mine ? 1.f : 0.f;
-      o[8 * NPTS] = theirs ? 1.f : 0.f;
-      o[9 * NPTS] = col == 0 ? 1.f : 0.f;
-      o[10 * NPTS] = mine ? h[k] : 0.f;
-      o[11 * NPTS] = theirs ? h[k] : 0.f;
-      o[12 * NPTS] = 0.f;
-      o[13 * NPTS] = 0.f;
-      o[14 * NPTS] = has_our ? (float)((d[k] >> sh_our) & 127u) : 10000.f;
-      o[15 * NPTS] = has_opp ? (float)((d[k] >> sh_opp) & 127u) : 10000.f;
-      GO_UNROLL
-      for (int pl = 16; pl < 25; ++pl) o[pl * NPTS] = 0.f;
-    }
-  }
+  const bool act_b = lane <= 26;
+
+#define GO_PLANE(pl, EXPR)                                                          \
+  do {                                                                              \
+    float v_[8];                                                                    \
+    GO_UNROLL                                                                       \
+    for (int i = 0; i < 8; ++i) {                                                   \
+      const uint32_t dd = d[i];                                                     \
+      const uint32_t col = dd & 3u, cls = (dd >> 2) & 3u;                           \
+      const bool mine = col == our, theirs = col == opp;                            \
+      const float hh = h[i];                                                        \
+      (void)cls; (void)mine; (void)theirs; (void)hh;                                \
+      v_[i] = (EXPR);                                                               \
+    }                                                                               \
+    const float4u a_ = {v_[0], v_[1], v_[2], v_[3]};                                \
+    const float4u b_ = {v_[4], v_[5], v_[6], v_[7]};                                \
+    *reinterpret_cast<float4u*>(out + (pl) * NPTS + qa) = a_;                       \
+    if (act_b) *reinterpret_cast<float4u*>(out + (pl) * NPTS + qb) = b_;            \
+  } while (0)
+
+  GO_PLANE(0, (mine && cls == 1) ? 1.f : 0.f);
+  GO_PLANE(1, (mine && cls == 2) ? 1.f : 0.f);
+  GO_PLANE(2, (mine && cls != 1 && cls != 2) ? 1.f : 0.f);  // literally "else", board_feature.cc:93
+  GO_PLANE(3, (theirs && cls == 1) ? 1.f : 0.f);
+  GO_PLANE(4, (theirs && cls == 2) ? 1.f : 0.f);
+  GO_PLANE(5, (theirs && cls != 1 && cls != 2) ? 1.f : 0.f);
+  GO_PLANE(6, (dd & 16u) ? 1.f : 0.f);
+  GO_PLANE(7, mine ? 1.f : 0.f);
+  GO_PLANE(8, theirs ? 1.f : 0.f);
+  GO_PLANE(9, col == 0 ? 1.f : 0.f);
+  GO_PLANE(10, mine ? hh : 0.f);
+  GO_PLANE(11, theirs ? hh : 0.f);
+  zero_range(out + 12 * NPTS, 2 * NPTS, lane);               // BORDER, POSITION_MARK: never filled
+  GO_PLANE(14, has_our ? (float)((dd >> sh_our) & 127u) : 10000.f);
+  GO_PLANE(15, has_opp ? (float)((dd >> sh_opp) & 127u) : 10000.f);
+  zero_range(out + 16 * NPTS, 9 * NPTS, lane);               // planes 16..24: never filled
+#undef GO_PLANE
 }
 
 __device__ __forceinline__ void write_legal(const Geo& g, int lane, const Masks& m, uint8_t* __restrict__ out) {

@@ -23,9 +23,13 @@ RESIGN = -2
 F_RANDOM_POLICY = 1
 F_AUTO_RESTART = 2
 F_SKIP_DONE = 4
+F_RESET_ILLEGAL = 8
+F_RESTART_AFTER_END = 16
+F_COLLECT = 32
 
 # scalar slots of the canonical view
 S_PLY, S_NEXT, S_BCAP, S_WCAP, S_LAST1, S_LAST2, S_LAST3, S_LAST4, S_KO_AGE, S_KO, S_KO_COLOR, S_DONE, S_GAME = range(13)
+S_SEQ = 14
 # stats slots
 (ST_GAMES, ST_BLACK_WINS, ST_WHITE_WINS, ST_DRAWS, ST_PLIES, ST_BCAP, ST_WCAP, ST_SUM_LEN2, ST_PLY_CAP_HITS,
  ST_MAX_LEN, ST_SUM_SCORE, ST_MOVES_APPLIED, ST_ILLEGAL) = range(13)
@@ -45,6 +49,14 @@ _SIGS = {
     "goenv_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goenv_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goenv_ply": (C.c_int, [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6 + [C.c_void_p]),
+    "goenv_ply_sel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32] + [C.c_void_p] * 8),
+    "goenv_collect_sel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "goenv_sample_policy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    "goenv_pointer_is_device": (C.c_int, [C.c_void_p]),
+    "goenv_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "goenv_sync": (C.c_int, [C.c_void_p]),
+    "goenv_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "goenv_device_free": (C.c_int, [C.c_void_p]),
     "goenv_playout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "goenv_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goenv_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -84,6 +96,23 @@ def load_library(path=LIB_PATH):
 
 class GoEnvError(RuntimeError):
     pass
+
+
+class SampleOut(C.Structure):
+    """goenv_sample_out: device arrays [count] (or NULL) for the per-sample sequencing record."""
+    _fields_ = [(k, C.c_void_p) for k in ("id", "seq", "game_counter", "last_terminal", "move_idx", "winner",
+                                          "aug_code", "game_record_idx")]
+    DTYPES = dict(id=torch.int32, seq=torch.int32, game_counter=torch.int32, last_terminal=torch.int8,
+                  move_idx=torch.int32, winner=torch.int32, aug_code=torch.int32, game_record_idx=torch.int32)
+
+    @classmethod
+    def from_tensors(cls, tensors):
+        o = cls()
+        for k, t in tensors.items():
+            if t.dtype != cls.DTYPES[k] or not t.is_contiguous():
+                raise GoEnvError("sample field %s must be a contiguous %s tensor" % (k, cls.DTYPES[k]))
+            setattr(o, k, t.data_ptr())
+        return o
 
 
 def _ptr(t):
@@ -182,6 +211,32 @@ class GoEnv:
         self._check(status_out, torch.int32, (self.n,), "status_out")
         self._chk(self.lib.goenv_ply(self._h, flags, _ptr(actions), _ptr(aug_codes), _ptr(feat_out), _ptr(legal_out),
                                      _ptr(actions_out), _ptr(status_out), self._stream()))
+
+    def _sel(self, idx, first, count):
+        if idx is not None:
+            self._check(idx, torch.int32, (idx.numel(),), "idx")
+            return _ptr(idx), 0, idx.numel()
+        return None, int(first), int(self.n - first if count is None else count)
+
+    def ply_sel(self, idx=None, first=0, count=None, flags=0, actions=None, aug_codes=None, feat_out=None,
+                legal_out=None, meta=None, actions_out=None, status_out=None):
+        """goenv_ply_sel: batch arrays are indexed by the selection row."""
+        ip, first, count = self._sel(idx, first, count)
+        m = SampleOut.from_tensors(meta) if meta is not None else None
+        self._chk(self.lib.goenv_ply_sel(self._h, ip, first, count, flags, _ptr(actions), _ptr(aug_codes),
+                                         _ptr(feat_out), _ptr(legal_out), C.byref(m) if m is not None else None,
+                                         _ptr(actions_out), _ptr(status_out), self._stream()))
+
+    def collect_sel(self, idx=None, first=0, count=None, aug_codes=None, feat_out=None, legal_out=None, meta=None):
+        ip, first, count = self._sel(idx, first, count)
+        m = SampleOut.from_tensors(meta) if meta is not None else None
+        self._chk(self.lib.goenv_collect_sel(self._h, ip, first, count, _ptr(aug_codes), _ptr(feat_out),
+                                             _ptr(legal_out), C.byref(m) if m is not None else None, self._stream()))
+
+    def sample_policy(self, pi, actions_out, idx=None, first=0, count=None, aug_codes=None):
+        ip, first, count = self._sel(idx, first, count)
+        self._chk(self.lib.goenv_sample_policy(self._h, ip, first, count, _ptr(pi), _ptr(aug_codes),
+                                               _ptr(actions_out), self._stream()))
 
     def playout(self, moves_out=None, nmoves_out=None):
         max_record = 0

@@ -31,6 +31,7 @@
 #ifndef GOENV_H_
 #define GOENV_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -65,7 +66,7 @@ enum {
   GOENV_S_DONE = 11,     /* ext: 1 = IsGameEnd (board.cc:1690), 2 = ply cap */
   GOENV_S_GAME = 12,     /* ext: games finished on this slot (game_counter) */
   GOENV_S_RSVD13 = 13,
-  GOENV_S_RSVD14 = 14,
+  GOENV_S_SEQ = 14,      /* ext: samples emitted for the current game (SeqInfo.seq) */
   GOENV_S_RSVD15 = 15
 };
 
@@ -93,6 +94,31 @@ enum {
 #define GOENV_F_AUTO_RESTART 2u  /* finished boards are scored, counted in the
                                     stats vector and restarted in place      */
 #define GOENV_F_SKIP_DONE 4u     /* finished boards are left untouched       */
+#define GOENV_F_RESET_ILLEGAL 8u /* an illegal external action restarts the
+                                    game in place ("No valid move ..., restarting
+                                    the game", go/game.cc:81-90); status 0    */
+#define GOENV_F_RESTART_AFTER_END 16u /* a move that ends the game (IsGameEnd /
+                                    ply cap) is followed at once by scoring,
+                                    stats and a restart in place; status 2    */
+#define GOENV_F_COLLECT 32u      /* also emit the sample's sequencing record
+                                    (goenv_sample_out) and advance seq         */
+
+/* Per-sample sequencing / label record that the reference copies field by field
+ * out of GameState (go/go_game_specific.h:59-114, keys of EntryFunc
+ * go/game_context.h:67-83).  Each pointer is a device array [count] or NULL.
+ * seq / game_counter / last_terminal follow SeqInfo (elf/common.h:11-19):
+ * seq counts samples of the current game, game_counter games finished on the
+ * slot, last_terminal = 1 on the first sample after a restart. */
+typedef struct goenv_sample_out {
+  int32_t* id;              /* board index inside this context              */
+  int32_t* seq;
+  int32_t* game_counter;
+  int8_t* last_terminal;    /* type "char" in the reference                  */
+  int32_t* move_idx;        /* _ply of the position (go/go_ai.h:82)          */
+  int32_t* winner;          /* 0 for live play (go/go_ai.h:83)               */
+  int32_t* aug_code;
+  int32_t* game_record_idx; /* -1 for live play                              */
+} goenv_sample_out;
 
 typedef struct goenv_ctx goenv_ctx;
 
@@ -168,6 +194,42 @@ int goenv_features(goenv_ctx* ctx, const int32_t* aug_codes, float* feat_out,
 int goenv_ply(goenv_ctx* ctx, uint32_t flags, const int64_t* actions, const int32_t* aug_codes,
               float* feat_out, uint8_t* legal_out, int32_t* actions_out, int32_t* status_out,
               void* stream);
+
+/* Selections.  The three calls below act on `count` boards: board of row b is
+ * idx[b] (device int32) when idx != NULL, else first + b.  Every batch array is
+ * indexed by the ROW b, so a collector's batch tensors can be filled from any
+ * subset of the resident boards (this is what replaces CollectorGroupT's
+ * per-key memcpy, elf/state_collector.h:251-301, elf/hist.h:71-121).
+ *
+ * goenv_ply_sel     = goenv_ply on the selection (+ optional sample record).
+ * goenv_collect_sel = AIWithCommT::Act's Prepare + extract (elf/ai.h:69-80,
+ *                     go/go_ai.h:79-87): planes, mask and, when meta != NULL, the
+ *                     sequencing record of the CURRENT positions; seq advances.
+ * goenv_sample_policy: the move selection the reference leaves to MCTS /
+ *                     Python (SURVEY 3.1 note ii): sample a legal point with
+ *                     probability proportional to floor(pi*2^24) (exact integer
+ *                     arithmetic, counter RNG); uniform cfg-2 policy when every
+ *                     weight is 0.  pi float32 [count][361] in the frame of
+ *                     aug_codes; actions_out int64 [count] in board frame. */
+int goenv_ply_sel(goenv_ctx* ctx, const int32_t* idx, int first, int count, uint32_t flags,
+                  const int64_t* actions, const int32_t* aug_codes, float* feat_out,
+                  uint8_t* legal_out, const goenv_sample_out* meta, int32_t* actions_out,
+                  int32_t* status_out, void* stream);
+int goenv_collect_sel(goenv_ctx* ctx, const int32_t* idx, int first, int count,
+                      const int32_t* aug_codes, float* feat_out, uint8_t* legal_out,
+                      const goenv_sample_out* meta, void* stream);
+int goenv_sample_policy(goenv_ctx* ctx, const int32_t* idx, int first, int count, const float* pi,
+                        const int32_t* aug_codes, int64_t* actions_out, void* stream);
+
+/* Memory helpers for hosts that do not link the HIP runtime themselves (the
+ * GameContext layer): pointer classification (EntryInfo.p may be host or
+ * device, SURVEY 8b "Ownership"), stream-ordered copy in either direction,
+ * stream sync, staging allocation on the context's device. */
+int goenv_pointer_is_device(const void* p);
+int goenv_copy(void* dst, const void* src, size_t bytes, void* stream);
+int goenv_sync(void* stream);
+int goenv_device_alloc(goenv_ctx* ctx, size_t bytes, void** out);
+int goenv_device_free(void* p);
 
 /* goenv_playout: random playouts to the end inside ONE persistent launch
  * (state stays in LDS between plies); stops per board at game end or at the

@@ -431,6 +431,33 @@ int goor_policy_move(const GoBoard* b, uint64_t seed, uint64_t board_id, uint64_
   return -1;
 }
 
+/* Restatement of goenv_sample_policy (an extension with no counterpart in the reference, which
+ * leaves move selection to MCTS / Python): integer weights floor(pi*2^24) over the legal points,
+ * r = rand % total, first point whose running sum exceeds r; all-zero weights -> cfg-2 policy.
+ * pi is indexed in the frame of `aug`. */
+int goor_sample_policy(const GoBoard* b, uint64_t seed, uint64_t board_id, uint64_t game, const float* pi, int aug) {
+  uint8_t mask[NP];
+  goor_legal(b, mask);
+  uint32_t w[NP];
+  uint64_t total = 0;
+  for (int p = 0; p < NP; ++p) {
+    w[p] = 0;
+    if (mask[p]) {
+      float f = pi[aug ? d4(aug, p / BS, p % BS) : p];
+      if (f > 0.f) {
+        float sc = f * 16777216.0f;
+        w[p] = sc >= 16777216.0f ? 16777216u : (uint32_t)sc;
+      }
+    }
+    total += w[p];
+  }
+  if (total == 0) return goor_policy_move(b, seed, board_id, game);
+  uint64_t r = goor_policy_rand(seed ^ 0xA5A5A5A55A5A5A5Aull, board_id, game, (uint64_t)b->ply) % total;
+  uint64_t run = 0;
+  for (int p = 0; p < NP; ++p) { run += w[p]; if (run > r) return p; }
+  return -1;
+}
+
 /* One full random playout; returns plies applied, records moves (may be NULL). */
 int goor_playout(GoBoard* b, uint64_t seed, uint64_t board_id, uint64_t game, int max_ply,
                  int16_t* moves, int max_record) {

@@ -164,6 +164,8 @@ class OracleBoard(_Board):
         lib.goor_aug_action.argtypes = [C.c_int, C.c_int]
         lib.goor_aug_action_inv.restype = C.c_int
         lib.goor_aug_action_inv.argtypes = [C.c_int, C.c_int]
+        lib.goor_sample_policy.restype = C.c_int
+        lib.goor_sample_policy.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, _f32p, C.c_int]
         lib.goor_playout.restype = C.c_int
         lib.goor_playout.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _i16p, C.c_int]
 
@@ -182,6 +184,9 @@ class OracleBoard(_Board):
     def aug_action_inv(cls, code, action):
         cls.api()
         return cls._lib.goor_aug_action_inv(code, action)
+
+    def sample_policy(self, seed, board_id, game, pi, aug=0):
+        return self._lib.goor_sample_policy(self.ptr, seed, board_id, game, np.ascontiguousarray(pi, np.float32), aug)
 
     def playout(self, seed, board_id, game=0, max_ply=722):
         moves = np.zeros(2048, np.int16)

@@ -1,0 +1,65 @@
+// Diagnostic microbenchmark: how fast can one wave per board write its 9025-float feature block
+// under different store shapes?  Not part of the product.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#define NP 361
+#define FB 9025
+
+__global__ __launch_bounds__(64) void p0_kmajor(float* out, int n) {
+  int b = blockIdx.x, lane = threadIdx.x;
+  float* o = out + (size_t)b * FB;
+  for (int k = 0; k < 6; ++k) { int q = lane + 64 * k; if (q < NP) {
+#pragma unroll
+      for (int pl = 0; pl < 25; ++pl) o[pl * NP + q] = (float)(pl + k); } }
+}
+__global__ __launch_bounds__(64) void p1_planemajor(float* out, int n) {
+  int b = blockIdx.x, lane = threadIdx.x;
+  float* o = out + (size_t)b * FB;
+#pragma unroll
+  for (int pl = 0; pl < 25; ++pl) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { int q = lane + 64 * k; if (q < NP) o[pl * NP + q] = (float)(pl + k); } }
+}
+typedef float f4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) uf4 { float x, y, z, w; };
+__global__ __launch_bounds__(64) void p2_planemajor_x4(float* out, int n) {
+  int b = blockIdx.x, lane = threadIdx.x;
+  float* o = out + (size_t)b * FB;
+#pragma unroll
+  for (int pl = 0; pl < 25; ++pl) {
+    float v = (float)pl;
+    uf4 val = {v, v + 1, v + 2, v + 3};
+    *(uf4*)(o + pl * NP + 4 * lane) = val;
+    if (lane < 26) *(uf4*)(o + pl * NP + 256 + 4 * lane) = val;
+    if (lane == 26) o[pl * NP + 360] = v;
+  }
+}
+// whole block as an aligned flat stream: head (<=3 floats), 16-B body, tail
+__global__ __launch_bounds__(64) void p3_flat_aligned(float* out, int n) {
+  int b = blockIdx.x, lane = threadIdx.x;
+  size_t s = (size_t)b * FB, e = s + FB;
+  size_t a = (s + 3) & ~(size_t)3, z = e & ~(size_t)3;
+  if (lane < (int)(a - s)) out[s + lane] = 1.f;
+  if (lane < (int)(e - z)) out[z + lane] = 2.f;
+  f4 val = {1.f, 2.f, 3.f, 4.f};
+  for (size_t i = a + 4 * lane; i < z; i += 256) *(f4*)(out + i) = val;
+}
+int main(int argc, char** argv) {
+  int n = argc > 1 ? atoi(argv[1]) : 65536, reps = argc > 2 ? atoi(argv[2]) : 20;
+  float* out; hipMalloc(&out, (size_t)n * FB * 4 + 64);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  void (*ks[4])(float*, int) = {p0_kmajor, p1_planemajor, p2_planemajor_x4, p3_flat_aligned};
+  const char* nm[4] = {"p0 k-major dword", "p1 plane-major dword", "p2 plane-major x4 (4B aligned)", "p3 flat aligned x4"};
+  for (int round = 0; round < 2; ++round)
+    for (int v = 0; v < 4; ++v) {
+      hipLaunchKernelGGL(ks[v], dim3(n), dim3(64), 0, 0, out, n);
+      hipDeviceSynchronize();
+      hipEventRecord(e0);
+      for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(ks[v], dim3(n), dim3(64), 0, 0, out, n);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+      if (round) printf("n=%d %-34s %8.3f us  %7.1f GB/s\n", n, nm[v], ms * 1e3, (double)n * FB * 4 / (ms * 1e-3) / 1e9);
+    }
+  return 0;
+}
