@@ -1,0 +1,202 @@
+"""Batch-level golden vectors (cfg 3: offline SGF replay -> feature planes + labels).
+
+Two steps, both run HERE (the container that mounts /root/reference):
+
+1. corpus: a small SGF corpus of OUR OWN games (oracle playouts written as SGF text, plus a few
+   deliberately awkward files: handicap, comments with escaped brackets, a variation, an illegal
+   move, a 9x9 game, a too-short game) next to the reference's only Go fixture go/sample1.sgf.
+   Written to tests/golden/corpus/ with the list file train.lst.
+2. streams: the UNMODIFIED reference `go_game` pybind module (oracle/_ref/go_game*.so, built by
+   `make -C oracle refmod` from the sources under /root/reference) is driven in offline mode over
+   that corpus with numpy buffers; for every game id the stream of samples it emits is recorded:
+   (seq, game_counter, last_terminal, move_idx, winner, aug_code, game_record_idx, offline_a[k],
+   FNV of the 9,025 plane floats).  Batch composition in the reference depends on thread timing,
+   per-game streams do not (each game owns its RNGs), so streams are what is pinned.
+
+Output: tests/golden/batch_streams.json (data only).
+"""
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from common import GOLDEN, dump_json  # noqa: E402
+from oracle.pyoracle import FNV_SEED, OracleBoard, fnv_planes  # noqa: E402
+
+CORPUS = os.path.join(GOLDEN, "corpus")
+
+
+def sgf_coord(a):
+    return "" if a < 0 else chr(ord("a") + a // 19) + chr(ord("a") + a % 19)
+
+
+def write_sgf(path, moves, handi=0, result="B+3.5", size=19, first="B", extra_head="", decorate=None):
+    col = first
+    body = []
+    for i, a in enumerate(moves):
+        node = ";%s[%s]" % (col, sgf_coord(a))
+        if decorate and i in decorate:
+            node += decorate[i]
+        body.append(node)
+        col = "W" if col == "B" else "B"
+    head = "(;GM[1]FF[4]SZ[%d]KM[7.5]%sRE[%s]PB[oracle black]PW[oracle white]%s\n" % (
+        size, ("HA[%d]" % handi) if handi else "", result, extra_head)
+    lines = ["".join(body[i:i + 10]) for i in range(0, len(body), 10)]
+    with open(path, "w") as f:
+        f.write(head + "\n".join(lines) + ")\n")
+
+
+def make_corpus():
+    os.makedirs(CORPUS, exist_ok=True)
+    names = ["sample1.sgf"]
+    with open(os.path.join(GOLDEN, "sample1.sgf")) as f, open(os.path.join(CORPUS, "sample1.sgf"), "w") as g:
+        g.write(f.read())
+
+    def playout(seed, bid, handi=0, cap=400):
+        b = OracleBoard()
+        if handi:
+            b.apply_handicap(handi)
+        return [int(m) for m in b.playout(seed, bid, 0, cap)]
+
+    # plain games; the playout ends in two passes so NumMoves stops at the first one (sgf.cc:45-51)
+    for i in range(4):
+        mv = playout(4242, i, 0, 300 + 40 * i)
+        write_sgf(os.path.join(CORPUS, "plain%d.sgf" % i), mv, result=["B+3.5", "W+R", "b+0.5", "W+12"][i])
+        names.append("plain%d.sgf" % i)
+    # handicap games: white moves first (PlaceHandicap leaves WHITE to move, board.cc:48-64)
+    for h in (2, 5, 9):
+        mv = playout(777, h, h, 260)
+        write_sgf(os.path.join(CORPUS, "handi%d.sgf" % h), mv, handi=h, result="W+R", first="W")
+        names.append("handi%d.sgf" % h)
+    # comments with escaped brackets, a side property and a variation (flattened by the parser)
+    mv = playout(99, 3, 0, 200)
+    deco = {5: "C[a comment with an escaped \\] bracket]", 9: "TR[aa][bb]", 17: "C[semi;colon (paren) inside]",
+            30: "(;B[aa];W[bb])"}
+    write_sgf(os.path.join(CORPUS, "decorated.sgf"), mv, result="B+R", decorate=deco,
+              extra_head="C[header comment \\] with escape]")
+    names.append("decorated.sgf")
+    # an illegal move (an occupied point) in the middle: next() reloads (offpolicy_loader.cc:123-125)
+    mv = playout(31337, 9, 0, 220)
+    mv = mv[:60] + [mv[10]] + mv[60:]
+    write_sgf(os.path.join(CORPUS, "illegal.sgf"), mv, result="W+2.5")
+    names.append("illegal.sgf")
+    # rejected by after_reload: wrong board size, too short (offpolicy_loader.cc:78)
+    write_sgf(os.path.join(CORPUS, "small9.sgf"), [a for a in playout(5, 5, 0, 60) if a // 19 < 9 and a % 19 < 9],
+              size=9)
+    names.append("small9.sgf")
+    write_sgf(os.path.join(CORPUS, "short.sgf"), playout(6, 6, 0, 300)[:7])
+    names.append("short.sgf")
+    # a pass in the middle truncates the record there
+    mv = playout(8, 8, 0, 200)
+    write_sgf(os.path.join(CORPUS, "midpass.sgf"), mv[:80] + [-1] + mv[80:])
+    names.append("midpass.sgf")
+    with open(os.path.join(CORPUS, "train.lst"), "w") as f:
+        f.write("\n".join(names) + "\n")
+    with open(os.path.join(CORPUS, "one.lst"), "w") as f:
+        f.write("sample1.sgf\n")
+    return names
+
+
+RUNS = [
+    dict(name="aug_random", seed=7, num_games=3, games_per_thread=3, data_aug=-1, start_ratio=0.5, ratio=0.0,
+         cutoff=-1, k=3, samples=600, lst="train.lst"),
+    dict(name="aug0_cutoff", seed=12345, num_games=1, games_per_thread=1, data_aug=0, start_ratio=0.9, ratio=0.3,
+         cutoff=70, k=3, samples=400, lst="train.lst"),
+    dict(name="k5_aug6", seed=99, num_games=2, games_per_thread=2, data_aug=6, start_ratio=0.2, ratio=0.2,
+         cutoff=-1, k=5, samples=300, lst="train.lst"),
+    dict(name="multi_game_one_file", seed=2024, num_games=3, games_per_thread=3, data_aug=-1, start_ratio=0.5,
+         ratio=0.1, cutoff=-1, k=3, samples=200, lst="one.lst"),
+]
+
+NP_TYPES = {"int32_t": "i4", "int64_t": "i8", "float": "f4", "unsigned char": "u1", "char": "i1"}
+KEYS = ["s", "offline_a", "id", "seq", "game_counter", "last_terminal", "move_idx", "winner", "aug_code",
+        "game_record_idx"]
+
+
+_KEEP_ALIVE = []
+
+
+def run_reference(go, cfg):
+    co = go.ContextOptions()
+    co.num_games = cfg["num_games"]
+    co.T = 1
+    co.num_collectors = 1
+    opt = go.GameOptions()
+    opt.seed = cfg["seed"]
+    opt.mode = "offline"
+    opt.list_filename = os.path.join(CORPUS, cfg["lst"])
+    opt.data_aug = cfg["data_aug"]
+    opt.start_ratio_pre_moves = cfg["start_ratio"]
+    opt.ratio_pre_moves = cfg["ratio"]
+    opt.move_cutoff = cfg["cutoff"]
+    opt.num_games_per_thread = cfg["games_per_thread"]
+    opt.num_future_actions = cfg["k"]
+    opt.verbose = False
+    GC = go.GameContext(co, opt)
+    gstat = GC.CreateGroupStat()
+    gstat.hist_len = 1
+    B = cfg["num_games"]
+    gid = GC.AddCollectors(B, 0, 0, gstat)
+    bufs = {}
+    for key in KEYS:
+        info = GC.GetTensorSpec(gid, key, 1)
+        assert info.key == key, key
+        v = np.zeros(info.sz, dtype=NP_TYPES[info.type])
+        info.p = v.ctypes.data
+        info.byte_size = v.size * v.dtype.itemsize
+        GC.AddTensor(gid, "input", info)
+        bufs[key] = v
+    GC.Start()
+    streams = {g: [] for g in range(B)}
+    while min(len(v) for v in streams.values()) < cfg["samples"]:
+        infos = GC.Wait(0)
+        n = len(infos.s)
+        for r in range(n):
+            g = int(bufs["id"][0, r])
+            streams[g].append([int(bufs[k][0, r]) for k in KEYS[2:]] +
+                              [[int(a) for a in bufs["offline_a"][0, r]]] +
+                              ["%016x" % fnv_planes(FNV_SEED, bufs["s"][0, r].reshape(-1))])
+        GC.Steps(infos)
+    # no GC.Stop(): the reference's teardown blocks on its worker threads.  Its threads keep writing
+    # into the buffers, so context and buffers stay alive until the caller (one process per
+    # configuration) leaves with os._exit
+    _KEEP_ALIVE.append((GC, bufs))
+    return {str(g): v[:cfg["samples"]] for g, v in streams.items()}
+
+
+def main():
+    so = glob.glob(os.path.join(ROOT, "oracle", "_ref", "go_game*.so"))
+    if not so:
+        raise SystemExit("oracle/_ref/go_game*.so missing: run `make -C oracle refmod` where /root/reference is mounted")
+    if len(sys.argv) > 2 and sys.argv[1] == "--run":     # child: one configuration, then leave hard
+        sys.path.insert(0, os.path.dirname(so[0]))
+        import go_game as go
+        st = run_reference(go, RUNS[int(sys.argv[2])])
+        dump_json(sys.argv[3], st)
+        sys.stdout.flush()
+        os._exit(0)
+    import subprocess
+    import tempfile
+    names = make_corpus()
+    out = dict(corpus=names, fields=KEYS[2:] + ["offline_a", "s_fnv"], runs=[])
+    for i, cfg in enumerate(RUNS):
+        with tempfile.TemporaryDirectory() as td:
+            tmp = os.path.join(td, "run.json")
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--run", str(i), tmp], check=True,
+                           stdout=subprocess.DEVNULL, timeout=600)
+            with open(tmp) as f:
+                st = json.load(f)
+        out["runs"].append(dict(cfg=cfg, streams=st))
+        print(cfg["name"], {g: len(v) for g, v in st.items()}, flush=True)
+    dump_json(os.path.join(GOLDEN, "batch_streams.json"), out)
+    print("written", os.path.join(GOLDEN, "batch_streams.json"))
+
+
+if __name__ == "__main__":
+    main()
