@@ -1,0 +1,849 @@
+// go_game.cc -- the `go_game` Python module of the MI355X build: same classes, methods, batch
+// keys, shapes and dtypes as the reference's pybind module (go/python_wrapper.cc:21-34,
+// elf/pybind_interface.h:18-95, go/game_context.h:22-112), with the games resident on the GPU.
+//
+// What is different underneath (on purpose): the reference runs one OS thread per game and one
+// per collector and hands samples over with condition variables and per-key memcpy
+// (elf/comm_template.h, elf/state_collector.h, elf/hist.h).  Here a GameContext owns ONE batch of
+// boards in HBM (libgoenv.so, include/goenv.h); Wait() forms the next batch of parked games,
+// lets the device write planes / masks / sequencing fields straight into the registered batch
+// tensors (device pointers are used in place, host pointers go through a staging copy), and
+// Steps() applies the replies to exactly those games with one launch.  No game threads exist.
+//
+// Host language: C++ + pybind11, as the reference.  GPU access only through the C-ABI.
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <ctime>
+#include <deque>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <random>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "device_env.h"
+#include "offline_loader.h"
+#include "sgf_record.h"
+
+namespace py = pybind11;
+using namespace gogame;
+
+// ------------------------------------------------------------------------------------------
+// option / descriptor PODs (field names as in the reference)
+// ------------------------------------------------------------------------------------------
+
+// elf/tree_search_options.h:21-55.  Carried for interface compatibility; tree search itself is
+// out of scope of this build.
+struct TSOptions {
+  int max_num_moves = 0;
+  int num_threads = 16;
+  int num_rollout_per_thread = 100;
+  bool verbose = false;
+  bool verbose_time = false;
+  std::string save_tree_filename;
+  bool persistent_tree = false;
+  std::string pick_method = "most_visited";
+  bool use_prior = false;
+  int pseudo_games = 0;
+};
+
+// elf/python_options_utils_cpp.h:20-55
+struct ContextOptions {
+  int num_games = 1;
+  int max_num_threads = 0;
+  int T = 1;
+  bool verbose_comm = false;
+  bool verbose_collector = false;
+  bool wait_per_group = false;
+  int num_collectors = 1;
+  TSOptions mcts_options;
+  void print() const {
+    std::cout << "#Game: " << num_games << std::endl;
+    std::cout << "#Max_thread: " << max_num_threads << std::endl;
+    std::cout << "#Collectors: " << num_collectors << std::endl;
+    std::cout << "T: " << T << std::endl;
+    if (verbose_comm) std::cout << "Comm Verbose On" << std::endl;
+    if (verbose_collector) std::cout << "Comm Collector On" << std::endl;
+    std::cout << "Wait per group: " << (wait_per_group ? "True" : "False") << std::endl;
+  }
+};
+
+// go/go_game_specific.h:16-57, plus the fields this build adds (all defaulted so that code
+// written for the reference runs unchanged).
+struct GameOptions {
+  unsigned int seed = 0;
+  int num_planes = GOENV_NUM_PLANES;
+  int num_future_actions = 3;
+  int num_games_per_thread = 300;
+  std::string mode;
+  bool use_mcts = false;
+  int data_aug = -1;
+  float start_ratio_pre_moves = 0.5f;
+  float ratio_pre_moves = 0.0f;
+  int move_cutoff = -1;
+  std::string list_filename;
+  bool verbose = false;
+  // --- extensions ---
+  int gpu = 0;                 // HIP device that holds the boards
+  float komi = 7.5f;           // for the win statistics only (go/sgf.h:92)
+  int ply_cap = 0;             // > 0: a selfplay game also ends (and restarts) beyond this ply
+  bool end_on_two_passes = false;  // selfplay: score + restart after IsGameEnd (the reference
+                                   // restarts only on an illegal move, go/game.cc:81-90)
+  bool signal_restart = false;     // selfplay: restart -> game_counter++, seq=0, last_terminal=1
+                                   // (the reference's Go loop never calls AIComm::Restart there)
+};
+
+// elf/state_collector.h:112-143
+struct EntryInfo {
+  std::string key;
+  std::string type;
+  std::vector<int> sz;
+  uint64_t p = 0;
+  std::size_t byte_size = 0;
+};
+
+// elf/comm_template.h:32-44
+struct GroupStat {
+  int gid = -1;
+  int hist_len = 1;
+  std::string name;
+  std::string info() const {
+    return "[gid=" + std::to_string(gid) + "][T=" + std::to_string(hist_len) + "][name=\"" + name + "\"]";
+  }
+};
+
+// elf/state_collector.h:30-40.  `s` holds the ids of the batch's games (the reference holds
+// pointers to their host-side history objects, which do not exist here).
+struct Infos {
+  int gid = -1;
+  std::vector<int> s;
+  int batchsize() const { return (int)s.size(); }
+};
+
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+struct KeySpec {
+  const char* key;
+  const char* type;  // type strings of elf/copier.hh:44-52
+  int elem;          // bytes per element
+  int inner;         // elements per sample (-1: num_future_actions)
+};
+
+// keys of GameState (go/go_game_specific.h:112) as EntryFunc reports them
+// (go/game_context.h:67-83) + the extension key `legal`.
+const KeySpec kKeys[] = {
+    {"s", "float", 4, GOENV_FEAT_FLOATS},      {"offline_a", "int64_t", 8, -1},
+    {"id", "int32_t", 4, 1},                   {"seq", "int32_t", 4, 1},
+    {"game_counter", "int32_t", 4, 1},         {"last_terminal", "char", 1, 1},
+    {"move_idx", "int32_t", 4, 1},             {"winner", "int32_t", 4, 1},
+    {"a", "int64_t", 8, 1},                    {"V", "float", 4, 1},
+    {"pi", "float", 4, GOENV_NUM_POINTS},      {"aug_code", "int32_t", 4, 1},
+    {"game_record_idx", "int32_t", 4, 1},      {"legal", "unsigned char", 1, GOENV_NUM_POINTS},
+};
+
+const KeySpec* find_key(const std::string& key) {
+  for (const KeySpec& k : kKeys)
+    if (key == k.key) return &k;
+  return nullptr;
+}
+
+struct Slot {
+  void* p = nullptr;
+  size_t bytes = 0;
+  bool device = false;
+};
+
+struct Collector {
+  int gid = 0;
+  int batchsize = 0;
+  int exclusive_id = 0;
+  int timeout_usec = 0;
+  GroupStat gstat;
+  std::map<std::string, Slot> input, reply;
+  bool busy = false;
+  std::vector<int> games;      // games parked in the outstanding batch
+  std::vector<int> boards;     // their boards (row order)
+  bool contiguous = false;     // boards are first, first+1, ...
+  long batches = 0, samples = 0;
+  // device staging
+  DevBuf idx, aug, actions, status, stage_s, stage_legal, stage_meta[8], stage_pi;
+};
+
+struct SeqState {  // SeqInfo, elf/common.h:11-19
+  int seq = 0, game_counter = 0;
+  char last_terminal = 0;
+};
+
+struct PendingSample {  // what extract() decided for the game's current sample
+  int loader = 0;
+  int aug = 0;
+  int seq = 0, game_counter = 0;
+  char last_terminal = 0;
+};
+
+const char* kMetaKeys[8] = {"id", "seq", "game_counter", "last_terminal", "move_idx", "winner", "aug_code",
+                            "game_record_idx"};
+
+}  // namespace
+
+class GameContext {
+ public:
+  GameContext(const ContextOptions& co, const GameOptions& opt) : co_(co), opt_(opt) {
+    if (co_.num_games <= 0) throw std::range_error("ContextOptions.num_games must be positive");
+    offline_ = !(opt_.mode == "online" || opt_.mode == "selfplay");
+    if (opt_.use_mcts)
+      throw std::range_error("use_mcts: tree search is outside this build (SURVEY 8f); run the policy directly");
+    if (offline_ && !opt_.list_filename.empty()) {
+      if (!corpus_.load_list(opt_.list_filename))
+        std::cout << "Loading " << opt_.list_filename << " failed!" << std::endl;
+      else {
+        std::cout << "Loading list_file: " << opt_.list_filename << std::endl;
+        std::cout << "Loaded: #Game: " << corpus_.size() << std::endl;
+      }
+    }
+  }
+  ~GameContext() { Stop(); }
+
+  // --- collectors (CommT::AddCollectors, elf/comm_template.h:170-181) ------------------------
+  GroupStat CreateGroupStat() const { return GroupStat(); }
+
+  int AddCollectors(int batchsize, int exclusive_id, int timeout_usec, const GroupStat& gstat) {
+    if (started_) throw std::range_error("AddCollectors after Start()");
+    if (batchsize <= 0) throw std::range_error("AddCollectors: batchsize must be positive");
+    if (gstat.hist_len != 1)
+      throw std::range_error("AddCollectors: hist_len " + std::to_string(gstat.hist_len) +
+                             " -- the device collector keeps T = 1 (what the Go scripts use)");
+    if (exclusive_id < 0 || exclusive_id > (int)groups_.size())
+      throw std::range_error("AddCollectors: exclusive_id out of order");
+    std::unique_ptr<Collector> c(new Collector());
+    c->gid = (int)collectors_.size();
+    c->batchsize = batchsize;
+    c->exclusive_id = exclusive_id;
+    c->timeout_usec = timeout_usec;
+    c->gstat = gstat;
+    c->gstat.gid = c->gid;
+    if (exclusive_id == (int)groups_.size()) groups_.emplace_back();
+    groups_[exclusive_id].members.push_back(c->gid);
+    if (groups_[exclusive_id].members.size() == 1) groups_[exclusive_id].name = gstat.name;
+    collectors_.push_back(std::move(c));
+    return (int)collectors_.size() - 1;
+  }
+
+  std::string GetCollectorInfos() const {
+    std::stringstream ss;
+    for (size_t i = 0; i < groups_.size(); ++i) {
+      ss << "Group " << i << ": " << std::endl;
+      for (int gid : groups_[i].members) {
+        const Collector& c = *collectors_[gid];
+        ss << "  Collector[" << gid << "] Batchsize: " << c.batchsize << " Info: " << c.gstat.info() << std::endl;
+      }
+    }
+    return ss.str();
+  }
+
+  // CollectorGroupT::GetEntry (elf/state_collector.h:200-206) + EntryFunc (go/game_context.h:67-83)
+  EntryInfo GetTensorSpec(int gid, const std::string& key, int T) {
+    const Collector& c = collector(gid);
+    EntryInfo e;
+    if (key.empty()) return e;
+    const KeySpec* k = find_key(key);
+    if (k) {
+      e.key = key;
+      e.type = k->type;
+    }
+    e.sz.push_back(T);
+    e.sz.push_back(c.batchsize);
+    if (k) {
+      if (key == "s") { e.sz.push_back(GOENV_NUM_PLANES); e.sz.push_back(19); e.sz.push_back(19); }
+      else if (k->inner == -1) e.sz.push_back(opt_.num_future_actions);
+      else if (k->inner > 1) e.sz.push_back(k->inner);
+    }
+    return e;
+  }
+
+  // CollectorGroupT::AddEntry (elf/state_collector.h:208-218)
+  void AddTensor(int gid, const std::string& input_reply, const EntryInfo& e) {
+    Collector& c = collector(gid);
+    std::map<std::string, Slot>* dst = nullptr;
+    if (input_reply == "input") dst = &c.input;
+    else if (input_reply == "reply") dst = &c.reply;
+    else throw std::range_error("Unknown input_reply " + input_reply);
+    const KeySpec* k = find_key(e.key);
+    if (!k) throw std::range_error("AddTensor: unknown key \"" + e.key + "\"");
+    const size_t inner = k->inner == -1 ? (size_t)opt_.num_future_actions : (size_t)k->inner;
+    const size_t want = (size_t)c.batchsize * inner * (size_t)k->elem;  // T = 1
+    if (e.p == 0 || e.byte_size != want)
+      throw std::range_error("AddTensor: \"" + e.key + "\" needs a buffer of " + std::to_string(want) +
+                             " bytes, got " + std::to_string(e.byte_size));
+    Slot s;
+    s.p = reinterpret_cast<void*>(e.p);
+    s.bytes = e.byte_size;
+    s.device = goenv_pointer_is_device(s.p) != 0;
+    (*dst)[e.key] = s;
+  }
+
+  std::map<std::string, int> GetParams() const {  // go/game_context.h:56-65
+    return {{"num_action", GOENV_NUM_POINTS},  {"board_size", GOENV_BOARD_SIZE},
+            {"num_planes", GOENV_NUM_PLANES},  {"num_future_actions", opt_.num_future_actions},
+            {"our_stone_plane", 7},            {"opponent_stone_plane", 8}};
+  }
+
+  int size() const { return co_.num_games; }
+  std::string Version() const { return "elf_amd.go_game/goenv-abi-" + std::to_string(goenv_version()); }
+  void SetStream(uint64_t stream) { stream_ = reinterpret_cast<void*>(stream); if (env_) env_->set_stream(stream_); }
+
+  // --- life cycle -------------------------------------------------------------------------------
+  void Start() {
+    if (started_) return;
+    if (collectors_.empty()) throw std::range_error("Start(): no collectors were added");
+    const int npt = offline_ ? std::max(1, opt_.num_games_per_thread) : 1;
+    if (offline_ && corpus_.size() == 0) throw std::range_error("Start(): offline mode needs a readable list_filename");
+    env_.reset(new DeviceEnv(opt_.gpu, co_.num_games * npt, opt_.seed ? opt_.seed : 1, opt_.komi, opt_.ply_cap));
+    env_->set_stream(stream_);
+    games_.clear();
+    games_.resize(co_.num_games);
+    for (auto& g : groups_) g.ready.clear();
+    const uint64_t base_seed = opt_.seed ? (uint64_t)opt_.seed : clock_seed();
+    for (int g = 0; g < co_.num_games; ++g) {
+      GameSlot& gs = games_[g];
+      // GoGame::GoGame, go/game.cc:20-34 (seed 0: clock-derived per game)
+      const uint64_t seed = opt_.seed ? base_seed : (base_seed + (uint64_t)g * 2341479ull) % 100000000ull;
+      gs.rng.seed((std::mt19937::result_type)seed);
+      if (offline_) {
+        OfflineOptions oo;
+        oo.num_future_actions = opt_.num_future_actions; oo.data_aug = opt_.data_aug;
+        oo.start_ratio_pre_moves = opt_.start_ratio_pre_moves; oo.ratio_pre_moves = opt_.ratio_pre_moves;
+        oo.move_cutoff = opt_.move_cutoff; oo.verbose = opt_.verbose;
+        for (int i = 0; i < npt; ++i) {
+          // go/game.cc:51: seed + game_idx * i * 997 + i * 13773 + 7, narrowed to int
+          const uint64_t ls = seed + (uint64_t)(int64_t)(g * i * 997 + i * 13773 + 7);
+          gs.loaders.emplace_back(new OfflineLoader(oo, &corpus_, env_.get(), g * npt + i, (uint32_t)ls));
+        }
+      }
+      gs.phase = (opt_.mode == "online" && group_of("human_actor") >= 0) ? 0 : 1;
+      produce_sample(g);
+    }
+    started_ = true;
+  }
+
+  void Stop() {
+    if (!started_) return;
+    if (env_) {
+      try { env_->sync(); } catch (...) {}
+    }
+    for (auto& c : collectors_) { c->busy = false; c->games.clear(); }
+    games_.clear();
+    env_.reset();
+    started_ = false;
+  }
+
+  // --- the batch loop (ContextT::Wait / Steps, elf/comm_template.h:363-365) ---------------------
+  Infos Wait(int timeout_usec) {
+    (void)timeout_usec;
+    if (co_.wait_per_group)
+      throw std::range_error("wait_batch error. group_id = -1 while #queue_per_group = " +
+                             std::to_string(collectors_.size()));
+    return wait_impl(-1);
+  }
+
+  Infos WaitGroup(int group_id, int timeout_usec) {
+    (void)timeout_usec;
+    if (!co_.wait_per_group || group_id < 0 || group_id >= (int)collectors_.size())
+      throw std::range_error("wait_batch error. group_id = " + std::to_string(group_id) +
+                             " while #queue_per_group = " + std::to_string(co_.wait_per_group ? collectors_.size() : 0));
+    return wait_impl(group_id);
+  }
+
+  void Steps(const Infos& infos) {
+    if (infos.gid < 0) return;  // timed-out Wait: nothing to release (comm_template.h:270)
+    Collector& c = collector(infos.gid);
+    if (!c.busy) throw std::range_error("Steps(): collector " + std::to_string(infos.gid) + " has no batch outstanding");
+    if (offline_) steps_offline(c);
+    else steps_play(c);
+    c.busy = false;
+    const int e = c.exclusive_id;
+    for (int g : c.games) produce_sample(g);
+    (void)e;
+    c.games.clear();
+    c.boards.clear();
+  }
+
+  void PrintSummary() const {
+    for (const auto& c : collectors_)
+      std::cout << "Collector[" << c->gid << "]: #batches " << c->batches << ", #samples " << c->samples << std::endl;
+  }
+
+  // --- extensions -------------------------------------------------------------------------------
+  // End-of-episode statistics vector (include/goenv.h GOENV_ST_*): finished-and-uncounted boards
+  // are scored first.  This is the buffer a multi-GPU job all-reduces.
+  std::vector<int64_t> Stats() {
+    need_env();
+    chk(goenv_finish(env_->ctx(), env_->stream()), "goenv_finish");
+    std::vector<int64_t> out(GOENV_NUM_STATS);
+    chk(goenv_stats_host(env_->ctx(), out.data(), env_->stream()), "goenv_stats_host");
+    return out;
+  }
+  uint64_t StatsPtr() { need_env(); return reinterpret_cast<uint64_t>(goenv_stats_ptr(env_->ctx())); }
+
+  std::string ShowBoard(int game_idx) {  // go/game_context.h:89-92
+    if (game_idx < 0 || game_idx >= co_.num_games) return "Invalid game_idx [" + std::to_string(game_idx) + "]";
+    need_env();
+    const int board = offline_ ? games_[game_idx].loaders[games_[game_idx].sample.loader]->board() : game_idx;
+    DevBuf col, sc;
+    col.ensure(env_->ctx(), GOENV_NUM_POINTS);
+    sc.ensure(env_->ctx(), 64);
+    chk(goenv_get_state_sel(env_->ctx(), nullptr, board, 1, col.as<uint8_t>(), nullptr, nullptr, nullptr,
+                            sc.as<int32_t>(), env_->stream()), "goenv_get_state_sel");
+    uint8_t color[GOENV_NUM_POINTS];
+    int32_t scal[16];
+    env_->d2h(color, col.get(), sizeof(color));
+    env_->d2h(scal, sc.get(), sizeof(scal));
+    env_->sync();
+    std::stringstream ss;
+    static const char* cols = "ABCDEFGHJKLMNOPQRST";
+    ss << "   ";
+    for (int x = 0; x < 19; ++x) ss << cols[x] << ' ';
+    ss << "\n";
+    for (int y = 18; y >= 0; --y) {
+      ss << (y + 1 < 10 ? " " : "") << y + 1 << ' ';
+      for (int x = 0; x < 19; ++x) {
+        const int p = x * 19 + y;
+        const char ch = color[p] == 1 ? 'X' : (color[p] == 2 ? 'O' : '.');
+        ss << ch << (scal[GOENV_S_LAST1] == p ? ')' : ' ');
+      }
+      ss << "\n";
+    }
+    ss << "ply " << scal[GOENV_S_PLY] << ", next " << (scal[GOENV_S_NEXT] == 1 ? "B" : "W") << ", captured by B/W "
+       << scal[GOENV_S_BCAP] << "/" << scal[GOENV_S_WCAP] << "\n";
+    return ss.str();
+  }
+
+ private:
+  struct GameSlot {
+    std::mt19937 rng;
+    std::vector<std::unique_ptr<OfflineLoader>> loaders;
+    SeqState seq;
+    PendingSample sample;
+    int phase = 1;      // online mode: 0 = human to move, 1 = actor to move
+    int ply = 1;        // host mirror of _ply for play modes that keep host sequencing
+  };
+  struct Group {
+    std::string name;
+    std::vector<int> members;
+    std::deque<int> ready;
+    size_t rr = 0;
+  };
+
+  ContextOptions co_;
+  GameOptions opt_;
+  bool offline_ = false;
+  bool started_ = false;
+  void* stream_ = nullptr;
+  SgfCorpus corpus_;
+  std::unique_ptr<DeviceEnv> env_;
+  std::vector<std::unique_ptr<Collector>> collectors_;
+  std::vector<Group> groups_;
+  std::vector<GameSlot> games_;
+  size_t rr_group_ = 0;
+
+  static uint64_t clock_seed() {
+    using namespace std::chrono;
+    const long ms = (long)duration_cast<milliseconds>(system_clock::now().time_since_epoch()).count();
+    return (uint64_t)((long)time(nullptr) * 1000 + ms);
+  }
+
+  void need_env() const {
+    if (!env_) throw std::range_error("the context is not started");
+  }
+
+  Collector& collector(int gid) {
+    if (gid < 0 || gid >= (int)collectors_.size()) throw std::range_error("no collector with gid " + std::to_string(gid));
+    return *collectors_[gid];
+  }
+
+  // exclusive group that takes samples named `name` (CondPerGroupT::check_name,
+  // elf/comm_template.h:46-54: an unnamed group takes everything)
+  int group_of(const std::string& name) const {
+    for (size_t i = 0; i < groups_.size(); ++i)
+      if (groups_[i].name.empty() || groups_[i].name == name) return (int)i;
+    return -1;
+  }
+
+  std::string sample_name(const GameSlot& gs) const {
+    if (offline_) return std::string();  // OfflineLoader::extract leaves GameState::name empty
+    return gs.phase == 0 ? "human_actor" : "actor";  // go/game.cc:46,60
+  }
+
+  // The game is ready to be sampled again: AI::Act's before_act + Prepare + the host part of
+  // extract (elf/ai.h:69-80,157-168); it is queued for the exclusive group that takes its name.
+  void produce_sample(int g) {
+    GameSlot& gs = games_[g];
+    if (offline_) {
+      gs.sample.loader = (int)(gs.rng() % gs.loaders.size());  // go/game.cc:96
+      OfflineLoader& ld = *gs.loaders[gs.sample.loader];
+      if (ld.just_started()) {  // before_act -> AIComm::Restart, go/offpolicy_loader.h:49-51
+        gs.seq.seq = 0; gs.seq.game_counter += 1; gs.seq.last_terminal = 1;
+      }
+      gs.sample.aug = 0;  // drawn in wait_impl, at extract time, after Prepare
+    }
+    const int e = group_of(sample_name(gs));
+    if (e < 0) throw std::range_error("no collector takes samples named \"" + sample_name(gs) + "\"");
+    groups_[e].ready.push_back(g);
+  }
+
+  Infos wait_impl(int only_gid) {
+    if (!started_) throw std::range_error("Wait() before Start()");
+    // pick a free collector whose group has parked games; full batches first
+    Collector* pick = nullptr;
+    for (int pass = 0; pass < 2 && !pick; ++pass) {
+      for (size_t k = 0; k < groups_.size() && !pick; ++k) {
+        Group& grp = groups_[(rr_group_ + k) % groups_.size()];
+        if (grp.ready.empty()) continue;
+        for (size_t j = 0; j < grp.members.size(); ++j) {
+          Collector& c = *collectors_[grp.members[(grp.rr + j) % grp.members.size()]];
+          if (c.busy || (only_gid >= 0 && c.gid != only_gid)) continue;
+          if (pass == 0 && (int)grp.ready.size() < c.batchsize) continue;
+          pick = &c;
+          grp.rr = (grp.rr + j + 1) % grp.members.size();
+          break;
+        }
+      }
+    }
+    Infos infos;
+    if (!pick) return infos;  // gid = -1, as a timed-out wait (elf/state_collector.h:91)
+    rr_group_ = (rr_group_ + 1) % groups_.size();
+    Collector& c = *pick;
+    Group& grp = groups_[c.exclusive_id];
+    const int n = std::min<int>(c.batchsize, (int)grp.ready.size());
+    c.games.assign(grp.ready.begin(), grp.ready.begin() + n);
+    grp.ready.erase(grp.ready.begin(), grp.ready.begin() + n);
+    fill_inputs(c);
+    c.busy = true;
+    c.batches += 1;
+    c.samples += n;
+    infos.gid = c.gid;
+    infos.s = c.games;
+    return infos;
+  }
+
+  // device pointer to write `key` rows into: the registered tensor itself, or staging
+  template <typename T>
+  T* out_ptr(Collector& c, const std::string& key, DevBuf& stage, size_t bytes, bool* staged) {
+    auto it = c.input.find(key);
+    if (it == c.input.end()) return nullptr;
+    if (it->second.device) return reinterpret_cast<T*>(it->second.p);
+    stage.ensure(env_->ctx(), bytes);
+    *staged = true;
+    return stage.as<T>();
+  }
+
+  void fill_inputs(Collector& c) {
+    const int n = (int)c.games.size();
+    c.boards.resize(n);
+    std::vector<int32_t> aug(n, 0);
+    std::vector<int32_t> meta[8];
+    std::vector<int64_t> off_a;
+    const bool host_meta = offline_ || opt_.mode == "online";
+    if (host_meta)
+      for (auto& m : meta) m.assign(n, 0);
+    if (offline_) off_a.assign((size_t)n * opt_.num_future_actions, 0);
+    for (int r = 0; r < n; ++r) {
+      const int g = c.games[r];
+      GameSlot& gs = games_[g];
+      if (offline_) {
+        OfflineLoader& ld = *gs.loaders[gs.sample.loader];
+        c.boards[r] = ld.board();
+        // Prepare (elf/ai_comm.h:62-67), then extract (offpolicy_loader.cc:128-145)
+        meta[1][r] = gs.seq.seq; meta[2][r] = gs.seq.game_counter; meta[3][r] = gs.seq.last_terminal;
+        gs.seq.seq += 1; gs.seq.last_terminal = 0;
+        meta[0][r] = g;
+        meta[7][r] = ld.curr_game();
+        meta[4][r] = ld.ply();
+        meta[5][r] = ld.winner_label();
+        gs.sample.aug = ld.draw_aug_code();
+        meta[6][r] = gs.sample.aug;
+        aug[r] = gs.sample.aug;
+        ld.future_actions(gs.sample.aug, &off_a[(size_t)r * opt_.num_future_actions]);
+      } else {
+        c.boards[r] = g;
+        if (host_meta) {  // online: DirectPredictAI / HumanPlayer extract, go/go_ai.h:79-87,106-113
+          meta[0][r] = g; meta[1][r] = gs.seq.seq; meta[2][r] = gs.seq.game_counter;
+          meta[3][r] = gs.seq.last_terminal;
+          gs.seq.seq += 1; gs.seq.last_terminal = 0;
+          meta[4][r] = gs.ply; meta[5][r] = 0; meta[6][r] = 0; meta[7][r] = -1;
+        }
+      }
+    }
+    c.contiguous = true;
+    for (int r = 1; r < n; ++r)
+      if (c.boards[r] != c.boards[0] + r) { c.contiguous = false; break; }
+    const int32_t* d_idx = nullptr;
+    if (!c.contiguous) {
+      c.idx.ensure(env_->ctx(), (size_t)n * 4);
+      env_->h2d(c.idx.get(), c.boards.data(), (size_t)n * 4);
+      d_idx = c.idx.as<int32_t>();
+    }
+    const int32_t* d_aug = nullptr;
+    if (offline_) {
+      c.aug.ensure(env_->ctx(), (size_t)n * 4);
+      env_->h2d(c.aug.get(), aug.data(), (size_t)n * 4);
+      d_aug = c.aug.as<int32_t>();
+    }
+    bool st_s = false, st_l = false, st_m[8] = {false, false, false, false, false, false, false, false};
+    float* d_s = out_ptr<float>(c, "s", c.stage_s, (size_t)n * GOENV_FEAT_FLOATS * 4, &st_s);
+    uint8_t* d_l = out_ptr<uint8_t>(c, "legal", c.stage_legal, (size_t)n * GOENV_NUM_POINTS, &st_l);
+    goenv_sample_out so;
+    std::memset(&so, 0, sizeof(so));
+    so.mode = opt_.signal_restart ? GOENV_SEQ_EPISODES : GOENV_SEQ_RUN_ON;
+    bool want_dev_meta = false;
+    if (!host_meta) {  // selfplay: the device keeps seq / game_counter per board
+      void** fields[8] = {(void**)&so.id, (void**)&so.seq, (void**)&so.game_counter, (void**)&so.last_terminal,
+                          (void**)&so.move_idx, (void**)&so.winner, (void**)&so.aug_code, (void**)&so.game_record_idx};
+      for (int k = 0; k < 8; ++k) {
+        const size_t eb = k == 3 ? 1 : 4;
+        *fields[k] = out_ptr<char>(c, kMetaKeys[k], c.stage_meta[k], (size_t)n * eb, &st_m[k]);
+        want_dev_meta |= *fields[k] != nullptr;
+      }
+    }
+    // the device always advances seq in selfplay mode, registered or not
+    const goenv_sample_out* meta_arg = host_meta ? nullptr : &so;
+    (void)want_dev_meta;
+    chk(goenv_collect_sel(env_->ctx(), d_idx, c.contiguous ? c.boards[0] : 0, n, d_aug, d_s, d_l, meta_arg,
+                          env_->stream()), "goenv_collect_sel");
+    bool need_sync = false;
+    auto flush = [&](const std::string& key, DevBuf& stage, bool staged, size_t bytes) {
+      if (!staged) return;
+      env_->d2h(c.input[key].p, stage.get(), bytes);
+      need_sync = true;
+    };
+    flush("s", c.stage_s, st_s, (size_t)n * GOENV_FEAT_FLOATS * 4);
+    flush("legal", c.stage_legal, st_l, (size_t)n * GOENV_NUM_POINTS);
+    for (int k = 0; k < 8; ++k) flush(kMetaKeys[k], c.stage_meta[k], st_m[k], (size_t)n * (k == 3 ? 1 : 4));
+    if (host_meta) {
+      for (int k = 0; k < 8; ++k) {
+        auto it = c.input.find(kMetaKeys[k]);
+        if (it == c.input.end()) continue;
+        if (k == 3) {
+          std::vector<int8_t> lt(n);
+          for (int r = 0; r < n; ++r) lt[r] = (int8_t)meta[3][r];
+          put(it->second, lt.data(), (size_t)n);
+        } else {
+          put(it->second, meta[k].data(), (size_t)n * 4);
+        }
+      }
+      auto it = c.input.find("offline_a");
+      if (it != c.input.end() && offline_) put(it->second, off_a.data(), off_a.size() * 8);
+    }
+    // host-resident tensors must be complete when Wait returns; device tensors are stream-ordered
+    if (need_sync) env_->sync();
+  }
+
+  // small host-produced field -> registered tensor (host: plain copy; device: staged H2D)
+  void put(const Slot& s, const void* src, size_t bytes) {
+    if (s.device) env_->h2d(s.p, src, bytes);
+    else std::memcpy(s.p, src, bytes);
+  }
+
+  // reply tensor `key` as a device pointer (staging a host tensor in); nullptr if not registered
+  const void* reply_ptr(Collector& c, const std::string& key, DevBuf& stage, size_t bytes) {
+    auto it = c.reply.find(key);
+    if (it == c.reply.end()) return nullptr;
+    if (it->second.device) return it->second.p;
+    stage.ensure(env_->ctx(), bytes);
+    env_->h2d(stage.get(), it->second.p, bytes);
+    return stage.get();
+  }
+
+  // selfplay / online: DirectPredictAI::handle_response + GoState::forward, restart on an
+  // illegal move (go/go_ai.h:89-93, go/game.cc:80-93)
+  void steps_play(Collector& c) {
+    const int n = (int)c.games.size();
+    const int32_t* d_idx = c.contiguous ? nullptr : c.idx.as<int32_t>();
+    const int first = c.contiguous ? c.boards[0] : 0;
+    const int64_t* d_a = (const int64_t*)reply_ptr(c, "a", c.actions, (size_t)n * 8);
+    if (!d_a) {
+      // the reference reads an unwritten GameState::a here (SURVEY 3.1 note ii); this build
+      // samples the move from the policy head over the legal points instead
+      const float* d_pi = (const float*)reply_ptr(c, "pi", c.stage_pi, (size_t)n * GOENV_NUM_POINTS * 4);
+      if (!d_pi) throw std::range_error("Steps(): the reply of collector " + std::to_string(c.gid) +
+                                        " carries neither \"a\" nor \"pi\"");
+      c.actions.ensure(env_->ctx(), (size_t)n * 8);
+      chk(goenv_sample_policy(env_->ctx(), d_idx, first, n, d_pi, nullptr, c.actions.as<int64_t>(), env_->stream()),
+          "goenv_sample_policy");
+      d_a = c.actions.as<int64_t>();
+    }
+    const bool online = opt_.mode == "online";
+    uint32_t flags = 0;
+    int human = 0;
+    for (int g : c.games) human += games_[g].phase == 0;
+    if (!(online && human)) flags |= GOENV_F_RESET_ILLEGAL;  // a human's illegal move is asked again
+    if (opt_.end_on_two_passes || opt_.ply_cap > 0) flags |= GOENV_F_RESTART_AFTER_END;
+    int32_t* d_status = nullptr;
+    if (online) {
+      c.status.ensure(env_->ctx(), (size_t)n * 4);
+      d_status = c.status.as<int32_t>();
+    }
+    chk(goenv_ply_sel(env_->ctx(), d_idx, first, n, flags, d_a, nullptr, nullptr, nullptr, nullptr, nullptr, d_status,
+                      env_->stream()), "goenv_ply_sel");
+    if (online) {  // host sequencing needs the legality of each move
+      std::vector<int32_t> st(n);
+      env_->d2h(st.data(), d_status, (size_t)n * 4);
+      env_->sync();
+      const bool has_human = group_of("human_actor") >= 0 && groups_[group_of("human_actor")].name == "human_actor";
+      for (int r = 0; r < n; ++r) {
+        GameSlot& gs = games_[c.games[r]];
+        if (gs.phase == 0) {
+          if (st[r] == 1) { gs.ply += 1; gs.phase = 1; }
+        } else {
+          if (st[r] == 1) gs.ply += 1;
+          else gs.ply = 1;  // reset
+          if (has_human) gs.phase = 0;
+        }
+      }
+    }
+  }
+
+  // offline: OfflineLoader::handle_response -> next() for every sample of the batch
+  // (go/offpolicy_loader.cc:147-152,120-126); the common case is one batched forward
+  void steps_offline(Collector& c) {
+    const int n = (int)c.games.size();
+    std::vector<int32_t> boards;
+    std::vector<int64_t> acts;
+    std::vector<OfflineLoader*> who;
+    for (int r = 0; r < n; ++r) {
+      GameSlot& gs = games_[c.games[r]];
+      OfflineLoader* ld = gs.loaders[gs.sample.loader].get();
+      const int a = ld->begin_next();
+      if (a == -100) continue;
+      boards.push_back(ld->board());
+      acts.push_back(a);
+      who.push_back(ld);
+    }
+    const int m = (int)boards.size();
+    if (m == 0) return;
+    c.idx.ensure(env_->ctx(), (size_t)m * 4);
+    c.actions.ensure(env_->ctx(), (size_t)m * 8);
+    c.status.ensure(env_->ctx(), (size_t)m * 4);
+    env_->h2d(c.idx.get(), boards.data(), (size_t)m * 4);
+    env_->h2d(c.actions.get(), acts.data(), (size_t)m * 8);
+    chk(goenv_ply_sel(env_->ctx(), c.idx.as<int32_t>(), 0, m, 0u, c.actions.as<int64_t>(), nullptr, nullptr, nullptr,
+                      nullptr, nullptr, c.status.as<int32_t>(), env_->stream()), "goenv_ply_sel");
+    std::vector<int32_t> st(m);
+    env_->d2h(st.data(), c.status.get(), (size_t)m * 4);
+    env_->sync();
+    for (int i = 0; i < m; ++i) who[i]->end_next(st[i] == 1);
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+
+PYBIND11_MODULE(go_game, m) {
+  m.doc() = "MI355X-native drop-in for ELF's go_game module (DarkForest Go environment)";
+
+  py::class_<TSOptions>(m, "TSOptions")
+      .def(py::init<>())
+      .def_readwrite("max_num_moves", &TSOptions::max_num_moves)
+      .def_readwrite("num_threads", &TSOptions::num_threads)
+      .def_readwrite("num_rollout_per_thread", &TSOptions::num_rollout_per_thread)
+      .def_readwrite("verbose", &TSOptions::verbose)
+      .def_readwrite("persistent_tree", &TSOptions::persistent_tree)
+      .def_readwrite("pick_method", &TSOptions::pick_method)
+      .def_readwrite("use_prior", &TSOptions::use_prior)
+      .def_readwrite("pseudo_games", &TSOptions::pseudo_games)
+      .def_readwrite("verbose_time", &TSOptions::verbose_time)
+      .def_readwrite("save_tree_filename", &TSOptions::save_tree_filename);
+
+  py::class_<ContextOptions>(m, "ContextOptions")
+      .def(py::init<>())
+      .def("print", &ContextOptions::print)
+      .def_readwrite("num_games", &ContextOptions::num_games)
+      .def_readwrite("max_num_threads", &ContextOptions::max_num_threads)
+      .def_readwrite("T", &ContextOptions::T)
+      .def_readwrite("verbose_comm", &ContextOptions::verbose_comm)
+      .def_readwrite("verbose_collector", &ContextOptions::verbose_collector)
+      .def_readwrite("wait_per_group", &ContextOptions::wait_per_group)
+      .def_readwrite("mcts_options", &ContextOptions::mcts_options)
+      .def_readwrite("num_collectors", &ContextOptions::num_collectors);
+
+  py::class_<GameOptions>(m, "GameOptions")
+      .def(py::init<>())
+      .def_readwrite("seed", &GameOptions::seed)
+      .def_readwrite("mode", &GameOptions::mode)
+      .def_readwrite("data_aug", &GameOptions::data_aug)
+      .def_readwrite("start_ratio_pre_moves", &GameOptions::start_ratio_pre_moves)
+      .def_readwrite("ratio_pre_moves", &GameOptions::ratio_pre_moves)
+      .def_readwrite("move_cutoff", &GameOptions::move_cutoff)
+      .def_readwrite("num_planes", &GameOptions::num_planes)
+      .def_readwrite("num_future_actions", &GameOptions::num_future_actions)
+      .def_readwrite("list_filename", &GameOptions::list_filename)
+      .def_readwrite("verbose", &GameOptions::verbose)
+      .def_readwrite("num_games_per_thread", &GameOptions::num_games_per_thread)
+      .def_readwrite("use_mcts", &GameOptions::use_mcts)
+      .def_readwrite("gpu", &GameOptions::gpu)
+      .def_readwrite("komi", &GameOptions::komi)
+      .def_readwrite("ply_cap", &GameOptions::ply_cap)
+      .def_readwrite("end_on_two_passes", &GameOptions::end_on_two_passes)
+      .def_readwrite("signal_restart", &GameOptions::signal_restart);
+
+  py::class_<EntryInfo>(m, "EntryInfo")
+      .def(py::init<>())
+      .def_readwrite("key", &EntryInfo::key)
+      .def_readwrite("type", &EntryInfo::type)
+      .def_readwrite("sz", &EntryInfo::sz)
+      .def_readwrite("p", &EntryInfo::p)
+      .def_readwrite("byte_size", &EntryInfo::byte_size);
+
+  py::class_<GroupStat>(m, "GroupStat")
+      .def(py::init<>())
+      .def("info", &GroupStat::info)
+      .def_readwrite("hist_len", &GroupStat::hist_len)
+      .def_readwrite("name", &GroupStat::name);
+
+  py::class_<Infos>(m, "Infos")
+      .def(py::init<>())
+      .def("batchsize", &Infos::batchsize)
+      .def_readwrite("gid", &Infos::gid)
+      .def_readwrite("s", &Infos::s);
+
+  py::class_<GameContext>(m, "GameContext")
+      .def(py::init<const ContextOptions&, const GameOptions&>())
+      .def("Wait", &GameContext::Wait, py::call_guard<py::gil_scoped_release>())
+      .def("WaitGroup", &GameContext::WaitGroup, py::call_guard<py::gil_scoped_release>())
+      .def("Steps", &GameContext::Steps, py::call_guard<py::gil_scoped_release>())
+      .def("Version", &GameContext::Version)
+      .def("PrintSummary", &GameContext::PrintSummary)
+      .def("CreateGroupStat", &GameContext::CreateGroupStat, py::return_value_policy::copy)
+      .def("AddCollectors", &GameContext::AddCollectors)
+      .def("Start", &GameContext::Start)
+      .def("Stop", &GameContext::Stop)
+      .def("__len__", &GameContext::size)
+      .def("AddTensor", &GameContext::AddTensor)
+      .def("GetTensorSpec", &GameContext::GetTensorSpec, py::return_value_policy::copy)
+      .def("GetCollectorInfos", &GameContext::GetCollectorInfos)
+      .def("GetParams", &GameContext::GetParams)
+      .def("ShowBoard", &GameContext::ShowBoard)
+      .def("SetStream", &GameContext::SetStream)
+      .def("Stats", &GameContext::Stats)
+      .def("StatsPtr", &GameContext::StatsPtr);
+
+  // host-side helpers exposed for tests and tools
+  m.def("parse_sgf", [](const std::string& text) {
+    const SgfRecord r = parse_sgf(text);
+    py::dict d;
+    d["ok"] = r.ok; d["board_size"] = r.board_size; d["handi"] = r.handi; d["komi"] = r.komi;
+    d["winner"] = r.winner; d["num_moves"] = r.num_moves;
+    d["moves"] = std::vector<int>(r.moves.begin(), r.moves.end());
+    d["players"] = std::vector<int>(r.players.begin(), r.players.end());
+    return d;
+  });
+  m.def("aug_action", &goenv_aug_action);        // BoardFeature::Coord2Action, go/board_feature.h:62-65
+  m.def("aug_action_inv", &goenv_aug_action_inv);  // BoardFeature::Action2Coord, :67-71
+}

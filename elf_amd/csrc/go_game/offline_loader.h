@@ -1,0 +1,186 @@
+// offline_loader.h -- SGF replay feeding the batch (the reference's OfflineLoader,
+// go/offpolicy_loader.{h,cc} on top of elf/replay_loader.h), with the board living on the GPU.
+//
+// What stays on the host: the SGF records, the position of each replay inside its record, the
+// std::mt19937 streams (same engine, same seeds, same call order as the reference, so that a
+// fixed GameOptions.seed gives the reference's samples) and the per-game sequencing.
+// What runs on the device: every rules operation -- Reset/ApplyHandicap (goenv_reset), the
+// pre-move fast-forward of after_reload (goenv_replay, one launch per reload), the per-sample
+// forward() (batched by the GameContext into one goenv_ply_sel launch) and Extract.
+#pragma once
+
+#include <map>
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "device_env.h"
+#include "sgf_record.h"
+
+namespace gogame {
+
+struct OfflineOptions {
+  int num_future_actions = 3;
+  int data_aug = -1;
+  float start_ratio_pre_moves = 0.5f;
+  float ratio_pre_moves = 0.0f;
+  int move_cutoff = -1;
+  bool verbose = false;
+};
+
+// The shared, lazily filled record store (OfflineLoader::InitSharedBuffer +
+// elf/shared_replay_buffer.h): list file -> names; records parsed on first use.
+class SgfCorpus {
+ public:
+  bool load_list(const std::string& list_filename) {
+    std::ifstream f(list_filename);
+    if (!f.is_open()) return false;
+    names_.clear();
+    for (std::string line; std::getline(f, line);) names_.push_back(line);
+    while (!names_.empty() && names_.back().empty()) names_.pop_back();
+    const size_t slash = list_filename.rfind('/');
+    dir_ = slash == std::string::npos ? std::string() : list_filename.substr(0, slash + 1);
+    return !names_.empty();
+  }
+  size_t size() const { return names_.size(); }
+  const std::string& name(size_t i) const { return names_[i]; }
+  const SgfRecord& get(size_t i) {
+    auto it = cache_.find(i);
+    if (it == cache_.end()) {
+      it = cache_.emplace(i, std::unique_ptr<SgfRecord>(new SgfRecord(load_sgf_file(dir_ + names_[i])))).first;
+    }
+    return *it->second;
+  }
+
+ private:
+  std::vector<std::string> names_;
+  std::string dir_;
+  std::map<size_t, std::unique_ptr<SgfRecord>> cache_;
+};
+
+// One replay: a record, a position in it and a board on the device.
+class OfflineLoader {
+ public:
+  OfflineLoader(const OfflineOptions& opt, SgfCorpus* corpus, DeviceEnv* env, int board, uint32_t seed)
+      : opt_(opt), corpus_(corpus), env_(env), board_(board), rng_(seed) {
+    reload();  // the reference reloads in the constructor (offpolicy_loader.cc:18-21)
+  }
+
+  int board() const { return board_; }
+  int ply() const { return ply_; }
+  bool just_started() const { return ply_ == 1; }  // GoState::JustStarted, go/go_state.h:55
+  int curr_game() const { return curr_game_; }
+  int winner_label() const {                       // offpolicy_loader.cc:132-133
+    const int w = rec_->winner;
+    return w == 1 ? 1 : (w == 2 ? -1 : 0);
+  }
+  // aug code of the next sample (offpolicy_loader.cc:135-137); draws from the replay's RNG
+  int draw_aug_code() {
+    int code = opt_.data_aug;
+    if (code == -1 || code >= 8) code = (int)(rng_() % 8);
+    return code;
+  }
+  // the next k record moves as actions in the augmented frame (save_forward_moves, :154-173)
+  void future_actions(int aug, int64_t* out) const {
+    for (int i = 0; i < opt_.num_future_actions; ++i) {
+      const int at = idx_ + i;
+      const int mv = at < (int)rec_->moves.size() ? rec_->moves[at] : -3;
+      int a = mv >= 0 ? goenv_aug_action(aug, mv) : -1;
+      if (a < 0 || a >= GOENV_NUM_POINTS) a = 0;  // "invalid action!" clamp, :162-169
+      out[i] = a;
+    }
+  }
+
+  // --- OfflineLoader::next (offpolicy_loader.cc:120-126), split so the common case can be
+  // batched across replays: begin_next() returns the action to forward on the device, or -100
+  // when the whole call was served by the slow path already; end_next(legal) finishes it.
+  int begin_next() {
+    if (need_reload()) {
+      reload();
+      const bool ok = env_->forward_one(board_, curr_move());
+      finish_forward(ok);
+      return -100;
+    }
+    return curr_move();
+  }
+  void end_next(bool legal) { finish_forward(legal); }
+
+ private:
+  OfflineOptions opt_;
+  SgfCorpus* corpus_;
+  DeviceEnv* env_;
+  int board_;
+  std::mt19937 rng_;
+  const SgfRecord* rec_ = nullptr;
+  int idx_ = 0;          // Sgf::iterator::_move_idx
+  int curr_game_ = 0;
+  int game_loaded_ = 0;
+  int ply_ = 1;
+
+  int curr_move() const { return idx_ < (int)rec_->moves.size() ? rec_->moves[idx_] : -1; }
+
+  bool need_reload() const {  // offpolicy_loader.cc:115-118
+    const bool done = idx_ >= (int)rec_->moves.size();
+    const int step_left = rec_->num_moves - idx_ - 1;
+    return done || step_left < opt_.num_future_actions || (opt_.move_cutoff >= 0 && idx_ >= opt_.move_cutoff);
+  }
+
+  void finish_forward(bool legal) {
+    if (!legal) reload();
+    else { ++idx_; ++ply_; }
+  }
+
+  // `count` calls of next() in a row (the pre-move loop of after_reload, :101).  Runs of moves
+  // that need no reload check are sent to the device as one replay launch.
+  void advance(int count) {
+    while (count > 0) {
+      if (need_reload()) {
+        reload();
+        const bool ok = env_->forward_one(board_, curr_move());
+        finish_forward(ok);
+        --count;
+        continue;
+      }
+      int run = 0;
+      while (run < count) {  // how many next() calls pass the reload test on host data alone
+        const int at = idx_ + run;
+        const bool done = at >= (int)rec_->moves.size();
+        const int left = rec_->num_moves - at - 1;
+        if (done || left < opt_.num_future_actions || (opt_.move_cutoff >= 0 && at >= opt_.move_cutoff)) break;
+        ++run;
+      }
+      const int applied = env_->replay_one(board_, rec_->moves.data() + idx_, run);
+      idx_ += applied;
+      ply_ += applied;
+      count -= applied;
+      if (applied < run) {  // that forward() failed: reload, the call is spent
+        reload();
+        --count;
+      }
+    }
+  }
+
+  // ReplayLoaderT::Reload + after_reload (elf/replay_loader.h:28-35, offpolicy_loader.cc:70-108)
+  void reload() {
+    while (true) {
+      curr_game_ = (int)(rng_() % corpus_->size());  // get_key, :110-113
+      rec_ = &corpus_->get((size_t)curr_game_);
+      idx_ = 0;
+      if (rec_->num_moves < 10 || rec_->board_size != GOENV_BOARD_SIZE) continue;
+      if (need_reload()) continue;
+      env_->reset_one(board_, rec_->handi);
+      ply_ = 1;
+      ++game_loaded_;
+      const float ratio = game_loaded_ == 1 ? opt_.start_ratio_pre_moves : opt_.ratio_pre_moves;
+      const float scaled = (float)rec_->num_moves * ratio;   // int * float, as in :97
+      int base = (int)((double)scaled + 0.5);
+      if (base == 0) base = 1;
+      const int pre_moves = (int)(rng_() % (unsigned long)base);
+      advance(pre_moves);
+      return;
+    }
+  }
+};
+
+}  // namespace gogame

@@ -86,9 +86,10 @@ __device__ __forceinline__ int board_of(const int32_t* idx, int first, int n_tot
 __device__ __forceinline__ void restart_in_place(WaveLds& L, const Geo& g, int lane, uint32_t lab[KCH],
                                                  uint32_t lastp[KCH], Scalars& s, Masks& m) {
   clear_board_lds(L, g, lane, lab, lastp);
-  const int game = s.game + 1;
+  const int game = s.game + 1, seqtot = s.seqtot;
   clear_scalars(s);
   s.game = game;
+  s.seqtot = seqtot;
   full_masks(m);
 }
 
@@ -97,16 +98,18 @@ __device__ __forceinline__ void restart_in_place(WaveLds& L, const Geo& g, int l
 __device__ __forceinline__ void emit_sample_meta(const goenv_sample_out& o, int b, int board, int lane,
                                                  Scalars& s, int aug) {
   if (lane == 0) {
+    const bool run_on = o.mode == GOENV_SEQ_RUN_ON;
     if (o.id) o.id[b] = board;
-    if (o.seq) o.seq[b] = s.seq;
-    if (o.game_counter) o.game_counter[b] = s.game;
-    if (o.last_terminal) o.last_terminal[b] = (int8_t)((s.seq == 0 && s.game > 0) ? 1 : 0);
+    if (o.seq) o.seq[b] = run_on ? s.seqtot : s.seq;
+    if (o.game_counter) o.game_counter[b] = run_on ? 0 : s.game;
+    if (o.last_terminal) o.last_terminal[b] = (int8_t)((!run_on && s.seq == 0 && s.game > 0) ? 1 : 0);
     if (o.move_idx) o.move_idx[b] = s.ply;  // gs.move_idx = state.GetPly(), go/go_ai.h:82
     if (o.winner) o.winner[b] = 0;
     if (o.aug_code) o.aug_code[b] = aug;
     if (o.game_record_idx) o.game_record_idx[b] = -1;
   }
   s.seq += 1;
+  s.seqtot += 1;
 }
 
 // One ply for one board held in LDS/registers.  Returns the action applied (-1 pass) or
@@ -115,14 +118,13 @@ __device__ __forceinline__ void emit_sample_meta(const goenv_sample_out& o, int 
 template <bool RANDOM>
 __device__ __forceinline__ int ply_body(WaveLds& L, const Geo& g, int lane, uint32_t lab[KCH],
                                         uint32_t lastp[KCH], Scalars& s, Masks& m, const PlyParams& P, int b,
-                                        int board) {
+                                        int board, long long av) {
   int a;
   if (RANDOM) {
     a = pick_random_move(m, lane, s, P.seed, (uint64_t)(P.id_base + board));
     a = __builtin_amdgcn_readfirstlane(a);
     STAMP(2);
   } else {
-    long long av = P.actions[b];
     a = (av < -2 || av >= NPTS) ? -4 : (int)av;
     a = __builtin_amdgcn_readfirstlane(a);
     if (a >= 0) {  // TryPlay: the stored legal ballot of the side to move
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(64) void k_ply(PlyParams P) {
   }
   int a = -3, status = -1;
   if (!skip) {
-    a = ply_body<RANDOM>(L, g, lane, lab, lastp, s, m, P, b, board);
+    a = ply_body<RANDOM>(L, g, lane, lab, lastp, s, m, P, b, board, RANDOM ? 0ll : (long long)P.actions[b]);
     status = (a == -4) ? 0 : 1;
     if (a == -4 && (P.flags & GOENV_F_RESET_ILLEGAL)) {
       // "No valid move ..., restarting the game", go/game.cc:81-90
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(64) void k_features(BoardRec* state, int n_total, c
   const int aug = aug_codes ? (aug_codes[b] & 7) : 0;
   if (collect) {
     emit_sample_meta(meta, b, board, lane, s, aug);
-    if (lane == 0) rec->sc[SC_SEQ] = s.seq;
+    if (lane == 0) { rec->sc[SC_SEQ] = s.seq; rec->sc[SC_SEQTOT] = s.seqtot; }
   }
   if (legal) {
     Masks m;
@@ -348,11 +350,12 @@ __global__ __launch_bounds__(64) void k_reset(BoardRec* state, int n_boards, con
   BoardRec* rec = state + b;
   Scalars s;
   load_scalars(rec, s);
-  const int game = s.game;
+  const int game = s.game, seqtot = s.seqtot;
   uint32_t lab[KCH], lastp[KCH];
   clear_board_lds(L, g, lane, lab, lastp);
   clear_scalars(s);
   s.game = game;
+  s.seqtot = seqtot;
   int h = handicap ? handicap[i] : 0;
   h = __builtin_amdgcn_readfirstlane(h);
   if (h >= 2 && h <= 9) {
@@ -374,14 +377,17 @@ __global__ __launch_bounds__(64) void k_reset(BoardRec* state, int n_boards, con
   store_board(rec, g, lane, lab, lastp, m, s);
 }
 
-__global__ __launch_bounds__(64) void k_get_state(const BoardRec* state, int n, uint8_t* color, int16_t* libs,
-                                                  int16_t* stones, uint16_t* last_placed, int32_t* scalars) {
+__global__ __launch_bounds__(64) void k_get_state(const BoardRec* state, int n_total, const int32_t* idx, int first,
+                                                  int n, uint8_t* color, int16_t* libs, int16_t* stones,
+                                                  uint16_t* last_placed, int32_t* scalars) {
   __shared__ WaveLds L;
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= n) return;
+  const int board = board_of(idx, first, n_total, b);
+  if (board < 0) return;
   Geo g;
   geo_init(g, lane);
-  const BoardRec* rec = state + b;
+  const BoardRec* rec = state + board;
   Scalars s;
   load_scalars(rec, s);
   uint32_t lab[KCH], lastp[KCH];
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(64) void k_get_state(const BoardRec* state, int n, 
   }
   if (scalars && lane < 16) {
     int v = rec->sc[lane];
-    if (lane == SC_COUNTED || lane == SC_R15) v = 0;
+    if (lane == SC_COUNTED) v = 0;
     scalars[(size_t)b * 16 + lane] = v;
   }
 }
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(64) void k_set_state(BoardRec* state, int n, const 
   s.ply = sc[0]; s.next = sc[1]; s.bcap = sc[2]; s.wcap = sc[3];
   s.l1 = sc[4]; s.l2 = sc[5]; s.l3 = sc[6]; s.l4 = sc[7];
   s.koage = sc[8] & 0xffff; s.ko = sc[9]; s.kocolor = sc[10];
-  s.done = sc[11]; s.game = sc[12]; s.counted = 0; s.seq = sc[14];
+  s.done = sc[11]; s.game = sc[12]; s.counted = 0; s.seq = sc[14]; s.seqtot = sc[15];
   Masks mk;
   unsigned long long eye[KCH];
   move_masks(L, g, lab, s, s.next, mk, eye);
@@ -503,12 +509,46 @@ __global__ __launch_bounds__(64) void k_playout(PlyParams P, int16_t* moves, int
   int cnt = 0;
   // exit condition every wave reaches: done flag, or the hard bound on iterations
   for (int it = 0; it < 4096 && !s.done; ++it) {
-    int a = ply_body<true>(L, g, lane, lab, lastp, s, m, P, b, b);
+    int a = ply_body<true>(L, g, lane, lab, lastp, s, m, P, b, b, 0ll);
     if (moves && cnt < max_record && lane == 0) moves[(size_t)b * max_record + cnt] = (int16_t)a;
     ++cnt;
   }
   store_board(rec, g, lane, lab, lastp, m, s);
   if (nmoves && lane == 0) nmoves[b] = cnt;
+}
+
+// Replay of given move lists (SGF records packed on the host): row b applies
+// moves[b*stride + 0 .. nmoves[b]) to its board with GoState::forward semantics and stops at the
+// first illegal move (go/offpolicy_loader.cc:120-126); napplied[b] = moves applied.  The board
+// stays in LDS/registers for the whole list.
+__global__ __launch_bounds__(64) void k_replay(PlyParams P, const int16_t* moves, int stride, const int32_t* nmoves,
+                                               int32_t* napplied) {
+  __shared__ WaveLds L;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= P.n) return;
+  const int board = board_of(P.idx, P.first, P.n_total, b);
+  if (board < 0) {
+    if (lane == 0 && napplied) napplied[b] = -1;
+    return;
+  }
+  Geo g;
+  geo_init(g, lane);
+  BoardRec* rec = P.state + board;
+  Scalars s;
+  load_scalars(rec, s);
+  uint32_t lab[KCH], lastp[KCH];
+  Masks m;
+  load_masks(rec, m);
+  load_board(rec, L, g, lane, lab, lastp);
+  int n = nmoves[b];
+  n = __builtin_amdgcn_readfirstlane(n < 0 ? 0 : (n > stride ? stride : n));
+  int cnt = 0;
+  for (; cnt < n; ++cnt) {  // bounded by the host-supplied list length
+    const int a = ply_body<false>(L, g, lane, lab, lastp, s, m, P, b, board, (long long)moves[(size_t)b * stride + cnt]);
+    if (a == -4) break;
+  }
+  if (cnt > 0) store_board(rec, g, lane, lab, lastp, m, s);
+  if (napplied && lane == 0) napplied[b] = cnt;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -621,8 +661,8 @@ int goenv_reset(goenv_ctx* c, const int32_t* idx, int n, const int32_t* handicap
 int goenv_get_state(goenv_ctx* c, uint8_t* color, int16_t* liberties, int16_t* stones, uint16_t* last_placed,
                     int32_t* scalars, void* stream) {
   if (!c) return fail("goenv_get_state: ctx is NULL");
-  hipLaunchKernelGGL(k_get_state, dim3(c->n), dim3(64), 0, S(stream), c->state, c->n, color, liberties, stones,
-                     last_placed, scalars);
+  hipLaunchKernelGGL(k_get_state, dim3(c->n), dim3(64), 0, S(stream), c->state, c->n, nullptr, 0, c->n, color,
+                     liberties, stones, last_placed, scalars);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -755,6 +795,40 @@ int goenv_device_alloc(goenv_ctx* c, size_t bytes, void** out) {
 
 int goenv_device_free(void* p) {
   if (p) HIPCHK(hipFree(p));
+  return 0;
+}
+
+int goenv_get_state_sel(goenv_ctx* c, const int32_t* idx, int first, int count, uint8_t* color, int16_t* liberties,
+                        int16_t* stones, uint16_t* last_placed, int32_t* scalars, void* stream) {
+  if (check_sel(c, idx, first, count, "goenv_get_state_sel")) return -1;
+  if (count == 0) return 0;
+  hipLaunchKernelGGL(k_get_state, dim3(count), dim3(64), 0, S(stream), c->state, c->n, idx, first, count, color,
+                     liberties, stones, last_placed, scalars);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int goenv_replay(goenv_ctx* c, const int32_t* idx, int first, int count, const int16_t* moves, int stride,
+                 const int32_t* nmoves, int32_t* napplied_out, void* stream) {
+  if (check_sel(c, idx, first, count, "goenv_replay")) return -1;
+  if (!moves || !nmoves || stride <= 0) return fail("goenv_replay: moves, nmoves and a positive stride are required");
+  if (count == 0) return 0;
+  PlyParams P = make_params(c, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  P.n = count; P.idx = idx; P.first = first;
+  P.max_ply = 0;  // a replayed record is not subject to the playout ply cap
+  hipLaunchKernelGGL(k_replay, dim3(count), dim3(64), 0, S(stream), P, moves, stride, nmoves, napplied_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int goenv_host_alloc(size_t bytes, void** out) {
+  if (!out) return fail("goenv_host_alloc: out is NULL");
+  HIPCHK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return 0;
+}
+
+int goenv_host_free(void* p) {
+  if (p) HIPCHK(hipHostFree(p));
   return 0;
 }
 

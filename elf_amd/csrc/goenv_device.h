@@ -49,7 +49,7 @@ constexpr int DIST_INF = 64;
 
 // scalar slots inside the record (same order as the canonical view, include/goenv.h)
 enum { SC_PLY = 0, SC_NEXT, SC_BCAP, SC_WCAP, SC_L1, SC_L2, SC_L3, SC_L4, SC_KOAGE, SC_KO,
-       SC_KOCOLOR, SC_DONE, SC_GAME, SC_COUNTED, SC_SEQ, SC_R15 };
+       SC_KOCOLOR, SC_DONE, SC_GAME, SC_COUNTED, SC_SEQ, SC_SEQTOT };
 
 // Packed per-board record in HBM: 1632 B, 16-B aligned, one contiguous read per wave.
 struct __attribute__((aligned(16))) BoardRec {
@@ -70,7 +70,7 @@ struct WaveLds {
 };
 
 struct Scalars {
-  int ply, next, bcap, wcap, l1, l2, l3, l4, koage, ko, kocolor, done, game, counted, seq;
+  int ply, next, bcap, wcap, l1, l2, l3, l4, koage, ko, kocolor, done, game, counted, seq, seqtot;
 };
 
 struct Geo {
@@ -112,6 +112,7 @@ __device__ __forceinline__ void load_scalars(const BoardRec* rec, Scalars& s) {
   s.l1 = sc[SC_L1]; s.l2 = sc[SC_L2]; s.l3 = sc[SC_L3]; s.l4 = sc[SC_L4];
   s.koage = sc[SC_KOAGE]; s.ko = sc[SC_KO]; s.kocolor = sc[SC_KOCOLOR];
   s.done = sc[SC_DONE]; s.game = sc[SC_GAME]; s.counted = sc[SC_COUNTED]; s.seq = sc[SC_SEQ];
+  s.seqtot = sc[SC_SEQTOT];
 }
 
 __device__ __forceinline__ void store_scalars(BoardRec* rec, const Scalars& s, int lane) {
@@ -125,7 +126,7 @@ __device__ __forceinline__ void store_scalars(BoardRec* rec, const Scalars& s, i
     case SC_KOAGE: v = s.koage; break;   case SC_KO: v = s.ko; break;
     case SC_KOCOLOR: v = s.kocolor; break; case SC_DONE: v = s.done; break;
     case SC_GAME: v = s.game; break;     case SC_COUNTED: v = s.counted; break;
-    case SC_SEQ: v = s.seq; break;
+    case SC_SEQ: v = s.seq; break;       case SC_SEQTOT: v = s.seqtot; break;
     default: v = 0;
   }
   if (lane < 16) rec->sc[lane] = v;

@@ -52,6 +52,11 @@ _SIGS = {
     "goenv_ply_sel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32] + [C.c_void_p] * 8),
     "goenv_collect_sel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5),
     "goenv_sample_policy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    "goenv_get_state_sel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]),
+    "goenv_replay": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                               C.c_void_p]),
+    "goenv_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "goenv_host_free": (C.c_int, [C.c_void_p]),
     "goenv_pointer_is_device": (C.c_int, [C.c_void_p]),
     "goenv_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "goenv_sync": (C.c_int, [C.c_void_p]),
@@ -101,13 +106,14 @@ class GoEnvError(RuntimeError):
 class SampleOut(C.Structure):
     """goenv_sample_out: device arrays [count] (or NULL) for the per-sample sequencing record."""
     _fields_ = [(k, C.c_void_p) for k in ("id", "seq", "game_counter", "last_terminal", "move_idx", "winner",
-                                          "aug_code", "game_record_idx")]
+                                          "aug_code", "game_record_idx")] + [("mode", C.c_uint32)]
     DTYPES = dict(id=torch.int32, seq=torch.int32, game_counter=torch.int32, last_terminal=torch.int8,
                   move_idx=torch.int32, winner=torch.int32, aug_code=torch.int32, game_record_idx=torch.int32)
 
     @classmethod
-    def from_tensors(cls, tensors):
+    def from_tensors(cls, tensors, mode=0):
         o = cls()
+        o.mode = mode
         for k, t in tensors.items():
             if t.dtype != cls.DTYPES[k] or not t.is_contiguous():
                 raise GoEnvError("sample field %s must be a contiguous %s tensor" % (k, cls.DTYPES[k]))
@@ -237,6 +243,15 @@ class GoEnv:
         ip, first, count = self._sel(idx, first, count)
         self._chk(self.lib.goenv_sample_policy(self._h, ip, first, count, _ptr(pi), _ptr(aug_codes),
                                                _ptr(actions_out), self._stream()))
+
+    def replay(self, moves, nmoves, napplied_out=None, idx=None, first=0, count=None):
+        """goenv_replay: moves int16 [count][stride], nmoves int32 [count]."""
+        ip, first, count = self._sel(idx, first, count)
+        self._check(moves, torch.int16, (count, moves.shape[1]), "moves")
+        self._check(nmoves, torch.int32, (count,), "nmoves")
+        self._check(napplied_out, torch.int32, (count,), "napplied_out")
+        self._chk(self.lib.goenv_replay(self._h, ip, first, count, _ptr(moves), moves.shape[1], _ptr(nmoves),
+                                        _ptr(napplied_out), self._stream()))
 
     def playout(self, moves_out=None, nmoves_out=None):
         max_record = 0

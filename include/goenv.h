@@ -67,7 +67,7 @@ enum {
   GOENV_S_GAME = 12,     /* ext: games finished on this slot (game_counter) */
   GOENV_S_RSVD13 = 13,
   GOENV_S_SEQ = 14,      /* ext: samples emitted for the current game (SeqInfo.seq) */
-  GOENV_S_RSVD15 = 15
+  GOENV_S_SEQ_TOTAL = 15 /* ext: samples emitted on this slot since creation        */
 };
 
 /* indices into the int64 stats[16] vector (end-of-episode statistics that the
@@ -118,7 +118,16 @@ typedef struct goenv_sample_out {
   int32_t* winner;          /* 0 for live play (go/go_ai.h:83)               */
   int32_t* aug_code;
   int32_t* game_record_idx; /* -1 for live play                              */
+  uint32_t mode;            /* GOENV_SEQ_* below                             */
 } goenv_sample_out;
+
+/* goenv_sample_out.mode.  EPISODES (0): a restart in place starts a new episode -- seq back to
+ * 0, game_counter + 1, last_terminal = 1 on its first sample (what AICommT::Restart does,
+ * elf/ai_comm.h:91-95).  RUN_ON: the reference's Go selfplay loop restarts a game WITHOUT
+ * calling Restart (go/game.cc:81-90), so there seq runs on, game_counter stays 0 and
+ * last_terminal stays 0; this mode reproduces that. */
+#define GOENV_SEQ_EPISODES 0u
+#define GOENV_SEQ_RUN_ON 1u
 
 typedef struct goenv_ctx goenv_ctx;
 
@@ -221,6 +230,20 @@ int goenv_collect_sel(goenv_ctx* ctx, const int32_t* idx, int first, int count,
 int goenv_sample_policy(goenv_ctx* ctx, const int32_t* idx, int first, int count, const float* pi,
                         const int32_t* aug_codes, int64_t* actions_out, void* stream);
 
+/* goenv_get_state_sel: goenv_get_state for a selection (rows = selection rows). */
+int goenv_get_state_sel(goenv_ctx* ctx, const int32_t* idx, int first, int count, uint8_t* color,
+                        int16_t* liberties, int16_t* stones, uint16_t* last_placed, int32_t* scalars,
+                        void* stream);
+
+/* goenv_replay: replay of packed move lists, the device half of OfflineLoader::next
+ * (go/offpolicy_loader.cc:120-126: s().forward(curr().GetCoord()), stop on an illegal
+ * move) and of the pre-move fast-forward in after_reload (:94-101).  Row b applies
+ * moves[b*stride + 0 .. nmoves[b]) (actions, -1 pass) to its board in ONE launch and
+ * stops at the first illegal move; napplied_out[b] = moves applied.  moves: device
+ * int16 [count][stride]; nmoves / napplied_out: device int32 [count]. */
+int goenv_replay(goenv_ctx* ctx, const int32_t* idx, int first, int count, const int16_t* moves,
+                 int stride, const int32_t* nmoves, int32_t* napplied_out, void* stream);
+
 /* Memory helpers for hosts that do not link the HIP runtime themselves (the
  * GameContext layer): pointer classification (EntryInfo.p may be host or
  * device, SURVEY 8b "Ownership"), stream-ordered copy in either direction,
@@ -230,6 +253,9 @@ int goenv_copy(void* dst, const void* src, size_t bytes, void* stream);
 int goenv_sync(void* stream);
 int goenv_device_alloc(goenv_ctx* ctx, size_t bytes, void** out);
 int goenv_device_free(void* p);
+/* pinned host staging memory (for small index / action / status arrays) */
+int goenv_host_alloc(size_t bytes, void** out);
+int goenv_host_free(void* p);
 
 /* goenv_playout: random playouts to the end inside ONE persistent launch
  * (state stays in LDS between plies); stops per board at game end or at the

@@ -114,6 +114,14 @@ RUNS = [
          ratio=0.1, cutoff=-1, k=3, samples=200, lst="one.lst"),
 ]
 
+QUIRK_TEXTS = [
+    "(;GM[1]SZ[19]RE[b+R]HA[4];B[pd];W[];B[tt];W[dd])", "(;GM[1];B[aa]\nW[bb];W[cc])",
+    "(;GM[1];B[aa]C[x \\] ;B[bb] y];W[cc])", "(;GM[1];B[aa](;W[bb])(;W[cc]))", "(;GM[1];B[aa];(;W[bb]);W[cc])",
+    "(;GM[1]\n SZ[19]  RE[ W+3.5];B[aa] ;W[ bb];B[cc\n])", "(;GM[1]C[a;b)c];B[aa];W[bb])",
+    "(;GM[1];B[aa]AB[cc][dd];W[bb])", "(;GM[1]SZ[13]KM[0.5]RE[W+R]\n;W[aa];B[sa];W[as];B[ss];W[ta])",
+    "(;GM[1])", "(;FF[4]RE[];B[jj];W[kk];B[];W[ll])",
+]
+
 NP_TYPES = {"int32_t": "i4", "int64_t": "i8", "float": "f4", "unsigned char": "u1", "char": "i1"}
 KEYS = ["s", "offline_a", "id", "seq", "game_counter", "last_terminal", "move_idx", "winner", "aug_code",
         "game_record_idx"]
@@ -184,6 +192,29 @@ def main():
     import subprocess
     import tempfile
     names = make_corpus()
+    # what the reference's Sgf::Load makes of every corpus file (oracle/_ref/libgoref.so)
+    from oracle.pyoracle import RefBoard
+    parsed = {}
+    for nm in names:
+        sg = RefBoard.sgf_load(os.path.join(CORPUS, nm))
+        parsed[nm] = dict(moves=[int(m) for m in sg["moves"]], num_moves=sg["num_moves"], winner=sg["winner"],
+                          handi=sg["handi"], board_size=sg["board_size"])
+    dump_json(os.path.join(GOLDEN, "corpus_parse.json"), parsed)
+    # small texts that exercise the parser's quirks, with the reference's reading of each
+    quirks = []
+    for text in QUIRK_TEXTS:
+        tmp = os.path.join(CORPUS, "_quirk_tmp.sgf")
+        with open(tmp, "w") as f:
+            f.write(text)
+        try:
+            sg = RefBoard.sgf_load(tmp)
+            res = dict(moves=[int(m) for m in sg["moves"]], num_moves=sg["num_moves"], winner=sg["winner"],
+                       handi=sg["handi"], board_size=sg["board_size"])
+        except RuntimeError:
+            res = None
+        os.unlink(tmp)
+        quirks.append(dict(text=text, ref=res))
+    dump_json(os.path.join(GOLDEN, "sgf_quirks.json"), quirks)
     out = dict(corpus=names, fields=KEYS[2:] + ["offline_a", "s_fnv"], runs=[])
     for i, cfg in enumerate(RUNS):
         with tempfile.TemporaryDirectory() as td:

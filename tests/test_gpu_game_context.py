@@ -1,0 +1,218 @@
+"""GPU tests of the GameContext boundary (elf_amd/go_game, C++/pybind11 over the C-ABI).
+
+* offline mode (cfg 3): the per-game sample streams -- labels, future moves and the 25 planes --
+  must equal, bit for bit, what the UNMODIFIED reference go_game module emitted for the same
+  GameOptions over the same SGF corpus (tests/golden/batch_streams.json).
+* selfplay / online mode: every batch row is checked against the CPU oracle replaying the same
+  actions; sequencing invariants of check.py:33-91.
+Host tensors (numpy, as the reference's callers pass) and device tensors (torch-ROCm) are both
+exercised."""
+import os
+
+import numpy as np
+import pytest
+
+from common import GOLDEN, assert_planes_equal, load_golden
+from oracle.pyoracle import FNV_SEED, OracleBoard, fnv_planes
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+NP_TYPES = {"int32_t": "i4", "int64_t": "i8", "float": "f4", "unsigned char": "u1", "char": "i1"}
+TORCH_TYPES = {"int32_t": torch.int32, "int64_t": torch.int64, "float": torch.float32, "unsigned char": torch.uint8,
+               "char": torch.int8}
+LABELS = ["id", "seq", "game_counter", "last_terminal", "move_idx", "winner", "aug_code", "game_record_idx"]
+
+
+@pytest.fixture(scope="module")
+def go():
+    from elf_amd import go_game
+    assert torch.cuda.is_available()
+    return go_game
+
+
+def register(gc, gid, which, keys, device):
+    bufs = {}
+    for key in keys:
+        info = gc.GetTensorSpec(gid, key, 1)
+        assert info.key == key
+        if device:
+            v = torch.zeros(*info.sz, dtype=TORCH_TYPES[info.type], device="cuda:0")
+            info.p, info.byte_size = v.data_ptr(), v.numel() * v.element_size()
+        else:
+            v = np.zeros(info.sz, dtype=NP_TYPES[info.type])
+            info.p, info.byte_size = v.ctypes.data, v.nbytes
+        gc.AddTensor(gid, which, info)
+        bufs[key] = v
+    return bufs
+
+
+def host(v):
+    return v.cpu().numpy() if isinstance(v, torch.Tensor) else v
+
+
+@pytest.mark.parametrize("device", [False, True])
+def test_offline_streams_equal_the_reference_module(go, device):
+    gold = load_golden("batch_streams.json")
+    for run in gold["runs"]:
+        cfg = run["cfg"]
+        co = go.ContextOptions()
+        co.num_games = cfg["num_games"]
+        opt = go.GameOptions()
+        opt.seed, opt.mode = cfg["seed"], "offline"
+        opt.list_filename = os.path.join(GOLDEN, "corpus", cfg["lst"])
+        opt.data_aug, opt.start_ratio_pre_moves, opt.ratio_pre_moves = cfg["data_aug"], cfg["start_ratio"], cfg["ratio"]
+        opt.move_cutoff, opt.num_games_per_thread, opt.num_future_actions = cfg["cutoff"], cfg["games_per_thread"], cfg["k"]
+        gc = go.GameContext(co, opt)
+        gs = gc.CreateGroupStat()
+        B = cfg["num_games"]
+        gid = gc.AddCollectors(B, 0, 0, gs)
+        bufs = register(gc, gid, "input", ["s", "offline_a"] + LABELS, device)
+        gc.Start()
+        n_check = min(cfg["samples"], 150 if device else cfg["samples"])
+        streams = {g: [] for g in range(B)}
+        while min(len(v) for v in streams.values()) < n_check:
+            infos = gc.Wait(0)
+            assert infos.gid == gid and len(infos.s) == B
+            h = {k: host(v) for k, v in bufs.items()}
+            for r in range(len(infos.s)):
+                g = int(h["id"][0, r])
+                assert g == infos.s[r]
+                streams[g].append([int(h[k][0, r]) for k in LABELS] + [[int(a) for a in h["offline_a"][0, r]]] +
+                                  ["%016x" % fnv_planes(FNV_SEED, h["s"][0, r].reshape(-1))])
+            gc.Steps(infos)
+        gc.Stop()
+        for g in range(B):
+            want = run["streams"][str(g)][:n_check]
+            got = streams[g][:n_check]
+            for i, (a, b) in enumerate(zip(got, want)):
+                assert a == b, "run %s game %d sample %d: got %s, reference %s" % (cfg["name"], g, i, a, b)
+
+
+@pytest.mark.parametrize("device", [False, True])
+def test_selfplay_loop_against_oracle(go, device):
+    """df_selfplay shape: `actor` collector, inputs s (+legal, labels), reply a.  The callback
+    plays a deterministic legal move (or sometimes an illegal one: the game restarts, as
+    go/game.cc:81-90).  Every row's planes/mask/move_idx are checked against an oracle board
+    replaying the same actions."""
+    N, B = 12, 4
+    co = go.ContextOptions()
+    co.num_games = N
+    opt = go.GameOptions()
+    opt.mode, opt.seed = "selfplay", 5
+    gc = go.GameContext(co, opt)
+    gs = gc.CreateGroupStat()
+    gs.name = "actor"
+    gids = [gc.AddCollectors(B, 0, 0, gs) for _ in range(2)]
+    ins = [register(gc, gid, "input", ["s", "legal"] + LABELS, device) for gid in gids]
+    outs = [register(gc, gid, "reply", ["a", "pi", "V"], device) for gid in gids]
+    gc.Start()
+    oracles = [OracleBoard() for _ in range(N)]
+    seq = [0] * N
+    rng = np.random.RandomState(0)
+    restarts = 0
+    for it in range(120):
+        infos = gc.Wait(0)
+        assert infos.gid in gids
+        k = gids.index(infos.gid)
+        h = {key: host(v) for key, v in ins[k].items()}
+        ids = list(infos.s)
+        assert len(set(ids)) == len(ids) == B                      # check.py: ids unique within a batch
+        acts = []
+        for r, g in enumerate(ids):
+            o = oracles[g]
+            assert h["id"][0, r] == g
+            assert h["seq"][0, r] == seq[g]                          # seq consecutive per game (run-on mode)
+            assert h["game_counter"][0, r] == 0 and h["last_terminal"][0, r] == 0
+            seq[g] += 1
+            assert h["move_idx"][0, r] == o.canonical()["scalars"][0]
+            assert h["winner"][0, r] == 0 and h["game_record_idx"][0, r] == -1 and h["aug_code"][0, r] == 0
+            assert np.array_equal(h["legal"][0, r], o.legal())
+            assert_planes_equal(h["s"][0, r], o.extract(0), "iter %d game %d" % (it, g))
+            legal = np.flatnonzero(o.legal())
+            if rng.rand() < 0.05 or legal.size == 0:
+                stones = np.flatnonzero(o.canonical()["color"])
+                a = int(stones[0]) if stones.size and rng.rand() < 0.7 else -1   # occupied point: illegal
+            else:
+                a = int(legal[rng.randint(legal.size)])
+            acts.append(a)
+            ok, _ = o.forward(a)
+            if not ok:
+                oracles[g] = OracleBoard()
+                restarts += 1
+        a_t = outs[k]["a"]
+        if device:
+            a_t.copy_(torch.tensor([acts], dtype=torch.int64))
+        else:
+            a_t[0, :] = acts
+        gc.Steps(infos)
+    assert restarts > 0
+    assert "X" in gc.ShowBoard(0) or "O" in gc.ShowBoard(0)
+    gc.Stop()
+
+
+def test_selfplay_policy_sampling_and_episode_signals(go):
+    """Reply carries only pi/V (the reference's selfplay descriptor, go/game.py:79-87): the move is
+    sampled on the device from pi over the legal points.  With signal_restart + end_on_two_passes
+    finished games are scored, counted and restarted with game_counter/last_terminal set."""
+    N = B = 16
+    co = go.ContextOptions()
+    co.num_games = N
+    opt = go.GameOptions()
+    opt.mode, opt.seed, opt.signal_restart, opt.end_on_two_passes, opt.ply_cap = "selfplay", 9, True, True, 60
+    gc = go.GameContext(co, opt)
+    gs = gc.CreateGroupStat()
+    gs.name = "actor"
+    gid = gc.AddCollectors(B, 0, 0, gs)
+    ins = register(gc, gid, "input", ["s", "legal", "id", "seq", "game_counter", "last_terminal", "move_idx"], True)
+    outs = register(gc, gid, "reply", ["pi", "V"], True)
+    gc.Start()
+    last_seq = [-1] * N
+    last_gc = [0] * N
+    terminals = 0
+    for it in range(150):
+        infos = gc.Wait(0)
+        s, legal = ins["s"][0], ins["legal"][0]
+        # a "policy": prefers empty points (plane 9), mass also on illegal points -- the sampler must mask
+        outs["pi"][0].copy_(s[:, 9].reshape(B, 361) + 0.01)
+        h = {k: v.cpu().numpy() for k, v in ins.items()}
+        for r in range(B):
+            g = int(h["id"][0, r])
+            if h["last_terminal"][0, r]:
+                terminals += 1
+                assert h["seq"][0, r] == 0 and h["game_counter"][0, r] == last_gc[g] + 1 and h["move_idx"][0, r] == 1
+            else:
+                assert h["seq"][0, r] == last_seq[g] + 1 and h["game_counter"][0, r] == last_gc[g]
+            last_seq[g], last_gc[g] = int(h["seq"][0, r]), int(h["game_counter"][0, r])
+            assert h["move_idx"][0, r] <= 61
+        gc.Steps(infos)
+    stats = gc.Stats()
+    assert terminals >= N and stats[0] >= terminals and stats[8] > 0     # games counted, ply-cap hits
+    gc.Stop()
+
+
+def test_gcwrapper_offline_training_batches(go):
+    """The Python caller's view (GCWrapper/Batch, train_df shape): device-resident batch tensors,
+    callback receives batch.hist(0) views."""
+    from elf_amd import go_loader
+    args = go_loader.add_arguments().parse_args(
+        ["--mode", "offline", "--num_games", "8", "--batchsize", "8", "--gpu", "0", "--seed", "7",
+         "--list_file", os.path.join(GOLDEN, "corpus", "train.lst"), "--num_games_per_thread", "2",
+         "--additional_labels", "id,seq,move_idx,aug_code,game_record_idx,winner"])
+    GC = go_loader.initialize(args)
+    seen = []
+
+    def train(batch):
+        b = batch.hist(0)
+        assert b["s"].is_cuda and tuple(b["s"].shape) == (8, 25, 19, 19) and tuple(b["offline_a"].shape) == (8, 3)
+        # stones planes are consistent with the empty plane
+        assert torch.all(b["s"][:, 7] + b["s"][:, 8] + b["s"][:, 9] == 1)
+        assert int(b["offline_a"].min()) >= 0 and int(b["offline_a"].max()) < 361
+        seen.append(b["move_idx"].cpu().tolist())
+
+    GC.reg_callback("train", train)
+    GC.Start()
+    for _ in range(20):
+        GC.Run()
+    GC.Stop()
+    assert len(seen) == 20 and GC.params["num_action"] == 361
