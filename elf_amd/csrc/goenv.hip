@@ -1,11 +1,13 @@
 // goenv.hip -- kernels and C-ABI of libgoenv.so (see include/goenv.h).
 //
-// Launch shape: one 64-thread workgroup (= one wavefront) per board, so a batch of
-// B boards is B workgroups; __syncthreads() inside the device code lowers to a
-// wave-level fence.  All kernels are stream-ordered on the caller's stream.
+// Launch shape: one workgroup of NW wavefronts per board (NW in {1,2,3,6}, goenv_device.h), so a
+// batch of B boards is B workgroups.  NW is chosen per launch from the batch size (small batches
+// are latency-bound and take more waves per board; large ones are HBM-bound and take one) or
+// pinned with goenv_set_waves_per_board.  All kernels are stream-ordered on the caller's stream.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -40,6 +42,8 @@ struct PlyParams {
   int64_t id_base;
   float komi;
   int max_ply;
+  float lut1;       // lut[1]
+  int zero_first;   // constant planes are stored at kernel start (small batches)
 };
 
 #ifdef GOENV_STAMPS
@@ -55,10 +59,10 @@ struct PlyParams {
 #define STAMP(i) do { } while (0)
 #endif
 
-// End-of-game accounting into the stats vector; lane 0 issues the atomics.
-__device__ __forceinline__ void account_game(unsigned long long* stats, int lane, const Scalars& s,
+// End-of-game accounting into the stats vector; thread 0 issues the atomics.
+__device__ __forceinline__ void account_game(unsigned long long* stats, int tid, const Scalars& s,
                                              int score, float komi) {
-  if (lane == 0) {
+  if (tid == 0) {
     const unsigned long long len = (unsigned long long)(s.ply - 1);
     atomicAdd(&stats[GOENV_ST_GAMES], 1ull);
     const float margin = (float)score - komi;
@@ -83,21 +87,22 @@ __device__ __forceinline__ int board_of(const int32_t* idx, int first, int n_tot
 
 // A game restarts in place: empty board, next game of this slot, seq 0 (AICommT::Restart ->
 // SeqInfo::NewEpisode, elf/ai_comm.h:91-95, elf/common.h:18).
-__device__ __forceinline__ void restart_in_place(WaveLds& L, const Geo& g, int lane, uint32_t lab[KCH],
-                                                 uint32_t lastp[KCH], Scalars& s, Masks& m) {
-  clear_board_lds(L, g, lane, lab, lastp);
+template <int NW>
+__device__ __forceinline__ void restart_in_place(BoardLds<NW>& L, const Geo<NW>& g, uint32_t lab[], uint32_t lastp[],
+                                                 Scalars& s, Masks& m, Own<NW>& o) {
+  clear_board_lds(L, g, lab, lastp);
   const int game = s.game + 1, seqtot = s.seqtot;
   clear_scalars(s);
   s.game = game;
   s.seqtot = seqtot;
-  full_masks(m);
+  full_masks(g, m, o);
 }
 
 // One sample's sequencing record (GameState::Prepare, go/go_game_specific.h:91-98 +
 // SeqInfo, elf/common.h:11-19): written for row b, then the board's seq advances.
-__device__ __forceinline__ void emit_sample_meta(const goenv_sample_out& o, int b, int board, int lane,
+__device__ __forceinline__ void emit_sample_meta(const goenv_sample_out& o, int b, int board, int tid,
                                                  Scalars& s, int aug) {
-  if (lane == 0) {
+  if (tid == 0) {
     const bool run_on = o.mode == GOENV_SEQ_RUN_ON;
     if (o.id) o.id[b] = board;
     if (o.seq) o.seq[b] = run_on ? s.seqtot : s.seq;
@@ -112,16 +117,16 @@ __device__ __forceinline__ void emit_sample_meta(const goenv_sample_out& o, int 
   s.seqtot += 1;
 }
 
-// One ply for one board held in LDS/registers.  Returns the action applied (-1 pass) or
-// -4 if the external action was illegal (state untouched).  On return `m` holds the masks of
-// the new side to move.
-template <bool RANDOM>
-__device__ __forceinline__ int ply_body(WaveLds& L, const Geo& g, int lane, uint32_t lab[KCH],
-                                        uint32_t lastp[KCH], Scalars& s, Masks& m, const PlyParams& P, int b,
-                                        int board, long long av) {
+// One ply for one board held in LDS/registers.  `m` = masks of the position (all words), `o`
+// receives this wave's words of the NEW position's masks.  Returns the action applied (-1 pass)
+// or -4 if the external action was illegal (state and `o` untouched).
+template <int NW, bool RANDOM>
+__device__ __forceinline__ int ply_body(BoardLds<NW>& L, const Geo<NW>& g, uint32_t lab[], uint32_t lastp[],
+                                        Scalars& s, const Masks& m, Own<NW>& o, const PlyParams& P, int board,
+                                        long long av) {
   int a;
   if (RANDOM) {
-    a = pick_random_move(m, lane, s, P.seed, (uint64_t)(P.id_base + board));
+    a = pick_random_move(m, g.lane, s, P.seed, (uint64_t)(P.id_base + board));
     a = __builtin_amdgcn_readfirstlane(a);
     STAMP(2);
   } else {
@@ -130,8 +135,8 @@ __device__ __forceinline__ int ply_body(WaveLds& L, const Geo& g, int lane, uint
     if (a >= 0) {  // TryPlay: the stored legal ballot of the side to move
       unsigned long long w = 0;
       GO_UNROLL
-      for (int k = 0; k < KCH; ++k)
-        if ((a >> 6) == k) w = m.legal[k];
+      for (int j = 0; j < NWORDS; ++j)
+        if ((a >> 6) == j) w = m.legal[j];
       if (!((w >> (a & 63)) & 1ull)) a = -4;
     }
     if (a == -4) return a;
@@ -139,113 +144,151 @@ __device__ __forceinline__ int ply_body(WaveLds& L, const Geo& g, int lane, uint
   if (a < 0) {
     advance(s, a, s.next);  // pass / resign: Play's early return, go/board.cc:1092-1095
   } else {
-    apply_move(L, g, lane, lab, lastp, s, a, s.next);
+    apply_move(L, g, lab, lastp, s, a, s.next);
   }
   STAMP(3);
-  unsigned long long eye[KCH];
-  move_masks(L, g, lab, s, s.next, m, eye);
+  move_masks(L, g, lab, s, s.next, o);
   s.done = game_end(s) ? 1 : ((P.max_ply > 0 && s.ply > P.max_ply) ? 2 : 0);
   s.counted = 0;
   return a;
 }
 
-template <bool RANDOM>
-__global__ __launch_bounds__(64) void k_ply(PlyParams P) {
-  __shared__ WaveLds L;
+template <int NW, bool RANDOM>
+__global__ __launch_bounds__(64 * NW) void k_ply(PlyParams P) {
+  __shared__ BoardLds<NW> L;
   const int b = blockIdx.x;
-  const int lane = threadIdx.x;
   if (b >= P.n) return;
+  Geo<NW> g;
+  geo_init(g);
+  constexpr int K = Geo<NW>::K;
   const int board = board_of(P.idx, P.first, P.n_total, b);
   if (board < 0) {
-    if (lane == 0 && P.status) P.status[b] = -2;
+    if (g.tid == 0 && P.status) P.status[b] = -2;
     return;
   }
   STAMP(0);
-  Geo g;
-  geo_init(g, lane);
   BoardRec* rec = P.state + board;
   Scalars s;
   load_scalars(rec, s);
-  uint32_t lab[KCH], lastp[KCH];
+  uint32_t lab[K], lastp[K];
   Masks m;
+  Own<NW> o;
   load_masks(rec, m);
-  load_board(rec, L, g, lane, lab, lastp);
+  own_from_masks(g, m, o);
+  load_board(rec, L, g, lab, lastp);
+  float hv_pre[K];
+  const int pre_ply = s.ply + 1;  // every accepted move, pass included, advances the ply by one
+  if (P.feat) {
+    history_preload(g, lastp, pre_ply, P.lut, hv_pre);
+    if (P.zero_first & 1) {
+      if (P.zero_first & 2) zero_planes<NW, true>(g, P.feat + (size_t)b * GOENV_FEAT_FLOATS);
+      else zero_planes<NW, false>(g, P.feat + (size_t)b * GOENV_FEAT_FLOATS);
+    }
+  }
   STAMP(1);
 
   bool skip = false;
   if (s.done) {
     if (P.flags & GOENV_F_AUTO_RESTART) {
-      if (!s.counted) account_game(P.stats, lane, s, tromp_taylor(L, g, lane, lab), P.komi);
-      restart_in_place(L, g, lane, lab, lastp, s, m);
+      if (!s.counted) account_game(P.stats, g.tid, s, tromp_taylor(L, g, lab), P.komi);
+      restart_in_place(L, g, lab, lastp, s, m, o);
     } else if (P.flags & GOENV_F_SKIP_DONE) {
       skip = true;
     }
   }
   int a = -3, status = -1;
   if (!skip) {
-    a = ply_body<RANDOM>(L, g, lane, lab, lastp, s, m, P, b, board, RANDOM ? 0ll : (long long)P.actions[b]);
+    a = ply_body<NW, RANDOM>(L, g, lab, lastp, s, m, o, P, board, RANDOM ? 0ll : (long long)P.actions[b]);
     status = (a == -4) ? 0 : 1;
     if (a == -4 && (P.flags & GOENV_F_RESET_ILLEGAL)) {
       // "No valid move ..., restarting the game", go/game.cc:81-90
-      restart_in_place(L, g, lane, lab, lastp, s, m);
+      restart_in_place(L, g, lab, lastp, s, m, o);
     } else if (a != -4 && s.done && (P.flags & GOENV_F_RESTART_AFTER_END)) {
-      account_game(P.stats, lane, s, tromp_taylor(L, g, lane, lab), P.komi);
-      restart_in_place(L, g, lane, lab, lastp, s, m);
+      account_game(P.stats, g.tid, s, tromp_taylor(L, g, lab), P.komi);
+      restart_in_place(L, g, lab, lastp, s, m, o);
       status = 2;
     }
     STAMP(4);
     const int aug = P.aug ? (P.aug[b] & 7) : 0;
-    if (P.flags & GOENV_F_COLLECT) emit_sample_meta(P.meta, b, board, lane, s, aug);
+    if (P.flags & GOENV_F_COLLECT) emit_sample_meta(P.meta, b, board, g.tid, s, aug);
     if (a != -4 || (P.flags & (GOENV_F_RESET_ILLEGAL | GOENV_F_COLLECT)))
-      store_board(rec, g, lane, lab, lastp, m, s);
+      store_board(rec, g, lab, lastp, o, s);
   }
   STAMP(5);
-  if (lane == 0) {
+  if (g.tid == 0) {
     if (P.actions_out) P.actions_out[b] = a;
     if (P.status) P.status[b] = status;
   }
   if (skip) return;
-  if (P.legal) write_legal(g, lane, m, P.legal + (size_t)b * NPTS);
+  if (P.legal) write_legal(g, o, P.legal + (size_t)b * NPTS);
   STAMP(6);
   if (P.feat) {
     const int aug = P.aug ? (P.aug[b] & 7) : 0;
-    write_features(L, g, lane, lab, lastp, s, aug, P.lut, P.feat + (size_t)b * GOENV_FEAT_FLOATS);
+    float* out = P.feat + (size_t)b * GOENV_FEAT_FLOATS;
+    switch (P.zero_first & 3) {
+      case 0: write_features<NW, true, false>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
+      case 1: write_features<NW, false, false>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
+      case 2: write_features<NW, true, true>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
+      default: write_features<NW, false, true>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
+    }
   }
   STAMP(7);
 }
 
 // Planes (+ mask, + sequencing record) of the CURRENT positions of the selected boards.
-__global__ __launch_bounds__(64) void k_features(BoardRec* state, int n_total, const int32_t* idx, int first,
-                                                 int n, const int32_t* aug_codes, const float* lut, float* feat,
-                                                 uint8_t* legal, goenv_sample_out meta, int collect) {
-  __shared__ WaveLds L;
-  const int b = blockIdx.x, lane = threadIdx.x;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_features(BoardRec* state, int n_total, const int32_t* idx, int first,
+                                                      int n, const int32_t* aug_codes, const float* lut, float* feat,
+                                                      uint8_t* legal, goenv_sample_out meta, int collect,
+                                                      float lut1, int zero_first) {
+  __shared__ BoardLds<NW> L;
+  const int b = blockIdx.x;
   if (b >= n) return;
   const int board = board_of(idx, first, n_total, b);
   if (board < 0) return;
-  Geo g;
-  geo_init(g, lane);
+  Geo<NW> g;
+  geo_init(g);
+  constexpr int K = Geo<NW>::K;
   BoardRec* rec = state + board;
   Scalars s;
   load_scalars(rec, s);
-  uint32_t lab[KCH], lastp[KCH];
-  load_board(rec, L, g, lane, lab, lastp);
+  uint32_t lab[K], lastp[K];
+  load_board(rec, L, g, lab, lastp);
+  float hv_pre[K];
+  if (feat) {
+    history_preload(g, lastp, s.ply, lut, hv_pre);
+    if (zero_first & 1) {
+      if (zero_first & 2) zero_planes<NW, true>(g, feat + (size_t)b * GOENV_FEAT_FLOATS);
+      else zero_planes<NW, false>(g, feat + (size_t)b * GOENV_FEAT_FLOATS);
+    }
+  }
   const int aug = aug_codes ? (aug_codes[b] & 7) : 0;
   if (collect) {
-    emit_sample_meta(meta, b, board, lane, s, aug);
-    if (lane == 0) { rec->sc[SC_SEQ] = s.seq; rec->sc[SC_SEQTOT] = s.seqtot; }
+    emit_sample_meta(meta, b, board, g.tid, s, aug);
+    if (g.tid == 0) { rec->sc[SC_SEQ] = s.seq; rec->sc[SC_SEQTOT] = s.seqtot; }
   }
   if (legal) {
     Masks m;
+    Own<NW> o;
     load_masks(rec, m);
-    write_legal(g, lane, m, legal + (size_t)b * NPTS);
+    own_from_masks(g, m, o);
+    write_legal(g, o, legal + (size_t)b * NPTS);
   }
-  if (feat) write_features(L, g, lane, lab, lastp, s, aug, lut, feat + (size_t)b * GOENV_FEAT_FLOATS);
+  if (feat) {
+    float* out = feat + (size_t)b * GOENV_FEAT_FLOATS;
+    switch (zero_first & 3) {
+      case 0: write_features<NW, true, false>(L, g, lab, lastp, s, aug, lut, out, hv_pre, s.ply, lut1); break;
+      case 1: write_features<NW, false, false>(L, g, lab, lastp, s, aug, lut, out, hv_pre, s.ply, lut1); break;
+      case 2: write_features<NW, true, true>(L, g, lab, lastp, s, aug, lut, out, hv_pre, s.ply, lut1); break;
+      default: write_features<NW, false, true>(L, g, lab, lastp, s, aug, lut, out, hv_pre, s.ply, lut1); break;
+    }
+  }
 }
 
 // Move selection from a policy head: sample p proportional to pi[p] over the LEGAL points, in exact
 // integer arithmetic (weights floor(pi * 2^24)), keyed by the counter RNG; all-zero weights fall
 // back to the cfg-2 random policy.  pi is indexed in the augmented frame of aug_codes[b].
+// One wavefront per board (reads only the record's masks; no board image needed).
 __global__ __launch_bounds__(64) void k_sample_policy(const BoardRec* state, int n_total, const int32_t* idx,
                                                       int first, int n, const float* pi, const int32_t* aug_codes,
                                                       int64_t* actions_out, uint64_t seed, int64_t id_base) {
@@ -263,10 +306,10 @@ __global__ __launch_bounds__(64) void k_sample_policy(const BoardRec* state, int
   load_masks(rec, m);
   const int aug = aug_codes ? (aug_codes[b] & 7) : 0;
   const float* row = pi + (size_t)b * NPTS;
-  uint32_t pre[KCH], sum[KCH];
+  uint32_t pre[NWORDS], sum[NWORDS];
   unsigned long long total = 0;
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
+  for (int k = 0; k < NWORDS; ++k) {
     const int p = lane + 64 * k;
     uint32_t w = 0;
     if (p < NPTS && ((m.legal[k] >> lane) & 1ull)) {
@@ -295,7 +338,7 @@ __global__ __launch_bounds__(64) void k_sample_policy(const BoardRec* state, int
     unsigned long long r = u % total;
     a = -1;
     GO_UNROLL
-    for (int k = 0; k < KCH; ++k) {
+    for (int k = 0; k < NWORDS; ++k) {
       if (a < 0) {
         if (r < sum[k]) {
           const unsigned long long hit = __ballot((unsigned long long)pre[k] > r);
@@ -309,24 +352,26 @@ __global__ __launch_bounds__(64) void k_sample_policy(const BoardRec* state, int
   if (lane == 0) actions_out[b] = a;
 }
 
-__global__ __launch_bounds__(64) void k_score(const BoardRec* state, int n, float* tt, float* fast) {
-  __shared__ WaveLds L;
-  const int b = blockIdx.x, lane = threadIdx.x;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_score(const BoardRec* state, int n, float* tt, float* fast) {
+  __shared__ BoardLds<NW> L;
+  const int b = blockIdx.x;
   if (b >= n) return;
-  Geo g;
-  geo_init(g, lane);
+  Geo<NW> g;
+  geo_init(g);
+  constexpr int K = Geo<NW>::K;
   const BoardRec* rec = state + b;
   Scalars s;
   load_scalars(rec, s);
-  uint32_t lab[KCH], lastp[KCH];
-  load_board(rec, L, g, lane, lab, lastp);
+  uint32_t lab[K], lastp[K];
+  load_board(rec, L, g, lab, lastp);
   if (fast) {
     int f = fast_score_cn(L, g, lab, s);
-    if (lane == 0) fast[b] = (float)f;
+    if (g.tid == 0) fast[b] = (float)f;
   }
   if (tt) {
-    int sc = tromp_taylor(L, g, lane, lab);
-    if (lane == 0) tt[b] = (float)sc;
+    int sc = tromp_taylor(L, g, lab);
+    if (g.tid == 0) tt[b] = (float)sc;
   }
 }
 
@@ -338,21 +383,23 @@ __constant__ int8_t c_handi_sets[10][10] = {
     {0, 1, 2, 3, 4, 5, -1}, {0, 1, 2, 3, 4, 5, 8, -1}, {0, 1, 2, 3, 4, 5, 6, 7, -1},
     {0, 1, 2, 3, 4, 5, 6, 7, 8, -1}};
 
-__global__ __launch_bounds__(64) void k_reset(BoardRec* state, int n_boards, const int32_t* idx, int n,
-                                              const int32_t* handicap) {
-  __shared__ WaveLds L;
-  const int i = blockIdx.x, lane = threadIdx.x;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_reset(BoardRec* state, int n_boards, const int32_t* idx, int n,
+                                                   const int32_t* handicap) {
+  __shared__ BoardLds<NW> L;
+  const int i = blockIdx.x;
   if (i >= n) return;
   const int b = idx ? idx[i] : i;
   if (b < 0 || b >= n_boards) return;
-  Geo g;
-  geo_init(g, lane);
+  Geo<NW> g;
+  geo_init(g);
+  constexpr int K = Geo<NW>::K;
   BoardRec* rec = state + b;
   Scalars s;
   load_scalars(rec, s);
   const int game = s.game, seqtot = s.seqtot;
-  uint32_t lab[KCH], lastp[KCH];
-  clear_board_lds(L, g, lane, lab, lastp);
+  uint32_t lab[K], lastp[K];
+  clear_board_lds(L, g, lab, lastp);
   clear_scalars(s);
   s.game = game;
   s.seqtot = seqtot;
@@ -364,47 +411,48 @@ __global__ __launch_bounds__(64) void k_reset(BoardRec* state, int n_boards, con
       if (e < 0) break;
       const int p = c_handi_xy[e][0] * BS + c_handi_xy[e][1];
       // PlaceHandicap, go/board.cc:48-64: TryPlay/Play as BLACK, then ply and last moves reset
-      if (s.ply <= 1 && move_is_legal(L, s, p, S_BLACK)) {
-        apply_move(L, g, lane, lab, lastp, s, p, S_BLACK);
+      bool ok = s.ply <= 1 && move_is_legal(L, s, p, S_BLACK);
+      ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;
+      if (ok) {
+        apply_move(L, g, lab, lastp, s, p, S_BLACK);
         s.ply = 1;
         s.l1 = s.l2 = s.l3 = s.l4 = -1;
       }
     }
   }
-  Masks m;
-  unsigned long long eye[KCH];
-  move_masks(L, g, lab, s, s.next, m, eye);
-  store_board(rec, g, lane, lab, lastp, m, s);
+  Own<NW> o;
+  move_masks(L, g, lab, s, s.next, o);
+  store_board(rec, g, lab, lastp, o, s);
 }
 
-__global__ __launch_bounds__(64) void k_get_state(const BoardRec* state, int n_total, const int32_t* idx, int first,
-                                                  int n, uint8_t* color, int16_t* libs, int16_t* stones,
-                                                  uint16_t* last_placed, int32_t* scalars) {
-  __shared__ WaveLds L;
-  const int b = blockIdx.x, lane = threadIdx.x;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_get_state(const BoardRec* state, int n_total, const int32_t* idx,
+                                                       int first, int n, uint8_t* color, int16_t* libs,
+                                                       int16_t* stones, uint16_t* last_placed, int32_t* scalars) {
+  __shared__ BoardLds<NW> L;
+  const int b = blockIdx.x;
   if (b >= n) return;
   const int board = board_of(idx, first, n_total, b);
   if (board < 0) return;
-  Geo g;
-  geo_init(g, lane);
+  Geo<NW> g;
+  geo_init(g);
+  constexpr int K = Geo<NW>::K;
   const BoardRec* rec = state + board;
-  Scalars s;
-  load_scalars(rec, s);
-  uint32_t lab[KCH], lastp[KCH];
-  load_board(rec, L, g, lane, lab, lastp);
-  rebuild_lib(L, g, lane, lab);  // exact liberty counts (the record keeps only min(lib,3))
+  uint32_t lab[K], lastp[K];
+  load_board(rec, L, g, lab, lastp);
+  rebuild_lib(L, g, lab);  // exact liberty counts (the record keeps only min(lib,3))
   // stones per root
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k)
+  for (int k = 0; k < K; ++k)
     if (g.p[k] < NPTS) L.desc[g.p[k]] = 0;
   WSYNC();
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k)
+  for (int k = 0; k < K; ++k)
     if (g.p[k] < NPTS && lab[k]) atomicAdd(&L.desc[lab[k] & ROOT_MASK], 1u);
   WSYNC();
   const size_t o = (size_t)b * NPTS;
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
+  for (int k = 0; k < K; ++k) {
     const int p = g.p[k];
     if (p < NPTS) {
       const uint32_t v = lab[k];
@@ -414,27 +462,30 @@ __global__ __launch_bounds__(64) void k_get_state(const BoardRec* state, int n_t
       if (last_placed) last_placed[o + p] = v ? (uint16_t)lastp[k] : 0;
     }
   }
-  if (scalars && lane < 16) {
-    int v = rec->sc[lane];
-    if (lane == SC_COUNTED) v = 0;
-    scalars[(size_t)b * 16 + lane] = v;
+  if (scalars && g.tid < 16) {
+    int v = rec->sc[g.tid];
+    if (g.tid == SC_COUNTED) v = 0;
+    scalars[(size_t)b * 16 + g.tid] = v;
   }
 }
 
-__global__ __launch_bounds__(64) void k_set_state(BoardRec* state, int n, const uint8_t* color,
-                                                  const uint16_t* last_placed, const int32_t* scalars) {
-  __shared__ WaveLds L;
-  const int b = blockIdx.x, lane = threadIdx.x;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_set_state(BoardRec* state, int n, const uint8_t* color,
+                                                       const uint16_t* last_placed, const int32_t* scalars) {
+  __shared__ BoardLds<NW> L;
+  const int b = blockIdx.x;
   if (b >= n) return;
-  Geo g;
-  geo_init(g, lane);
+  Geo<NW> g;
+  geo_init(g);
+  constexpr int K = Geo<NW>::K;
   BoardRec* rec = state + b;
   const size_t o = (size_t)b * NPTS;
-  uint32_t lab[KCH], lastp[KCH];
-  fill_rim(L, lane);
+  uint32_t lab[K], lastp[K];
+  fill_rim(L, g.tid);
+  board_any_init(L, g);
   WSYNC();
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
+  for (int k = 0; k < K; ++k) {
     lab[k] = 0; lastp[k] = 0;
     if (g.p[k] < NPTS) {
       uint32_t col = color[o + g.p[k]];
@@ -449,7 +500,7 @@ __global__ __launch_bounds__(64) void k_set_state(BoardRec* state, int n, const 
   for (int iter = 0; iter < 2 * NPTS; ++iter) {
     bool changed = false;
     GO_UNROLL
-    for (int k = 0; k < KCH; ++k) {
+    for (int k = 0; k < K; ++k) {
       if (g.p[k] < NPTS && lab[k]) {
         uint32_t n4[4];
         nbr4(L, g.c[k], n4);
@@ -459,97 +510,138 @@ __global__ __launch_bounds__(64) void k_set_state(BoardRec* state, int n, const 
           if (col_of(n4[i]) == col_of(lab[k]) && n4[i] < m) m = n4[i];
         if (m != lab[k]) { lab[k] = m; L.lab[g.c[k]] = (uint16_t)m; changed = true; }
       }
-      WSYNC();
     }
-    if (!__any(changed)) break;
+    if (!board_any(L, g, changed, iter)) break;
   }
-  rebuild_lib(L, g, lane, lab);
+  WSYNC();
+  rebuild_lib(L, g, lab);
   Scalars s;
   const int32_t* sc = scalars + (size_t)b * 16;
   s.ply = sc[0]; s.next = sc[1]; s.bcap = sc[2]; s.wcap = sc[3];
   s.l1 = sc[4]; s.l2 = sc[5]; s.l3 = sc[6]; s.l4 = sc[7];
   s.koage = sc[8] & 0xffff; s.ko = sc[9]; s.kocolor = sc[10];
   s.done = sc[11]; s.game = sc[12]; s.counted = 0; s.seq = sc[14]; s.seqtot = sc[15];
-  Masks mk;
-  unsigned long long eye[KCH];
-  move_masks(L, g, lab, s, s.next, mk, eye);
-  store_board(rec, g, lane, lab, lastp, mk, s);
+  Own<NW> mk;
+  move_masks(L, g, lab, s, s.next, mk);
+  store_board(rec, g, lab, lastp, mk, s);
 }
 
-__global__ __launch_bounds__(64) void k_finish(BoardRec* state, int n, unsigned long long* stats, float komi) {
-  __shared__ WaveLds L;
-  const int b = blockIdx.x, lane = threadIdx.x;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_finish(BoardRec* state, int n, unsigned long long* stats, float komi) {
+  __shared__ BoardLds<NW> L;
+  const int b = blockIdx.x;
   if (b >= n) return;
   BoardRec* rec = state + b;
   Scalars s;
   load_scalars(rec, s);
-  if (!s.done || s.counted) return;
-  Geo g;
-  geo_init(g, lane);
-  uint32_t lab[KCH], lastp[KCH];
-  load_board(rec, L, g, lane, lab, lastp);
-  account_game(stats, lane, s, tromp_taylor(L, g, lane, lab), komi);
-  if (lane == 0) rec->sc[SC_COUNTED] = 1;
+  if (!s.done || s.counted) return;  // uniform over the workgroup: no barrier is skipped by a part of it
+  Geo<NW> g;
+  geo_init(g);
+  constexpr int K = Geo<NW>::K;
+  uint32_t lab[K], lastp[K];
+  load_board(rec, L, g, lab, lastp);
+  account_game(stats, g.tid, s, tromp_taylor(L, g, lab), komi);
+  if (g.tid == 0) rec->sc[SC_COUNTED] = 1;
 }
 
 // Persistent random playout: the board stays in LDS/registers for the whole game.
-__global__ __launch_bounds__(64) void k_playout(PlyParams P, int16_t* moves, int max_record, int32_t* nmoves) {
-  __shared__ WaveLds L;
-  const int b = blockIdx.x, lane = threadIdx.x;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_playout(PlyParams P, int16_t* moves, int max_record, int32_t* nmoves) {
+  __shared__ BoardLds<NW> L;
+  const int b = blockIdx.x;
   if (b >= P.n) return;
-  Geo g;
-  geo_init(g, lane);
+  Geo<NW> g;
+  geo_init(g);
+  constexpr int K = Geo<NW>::K;
   BoardRec* rec = P.state + b;
   Scalars s;
   load_scalars(rec, s);
-  uint32_t lab[KCH], lastp[KCH];
+  uint32_t lab[K], lastp[K];
   Masks m;
+  Own<NW> o;
   load_masks(rec, m);
-  load_board(rec, L, g, lane, lab, lastp);
+  own_from_masks(g, m, o);
+  load_board(rec, L, g, lab, lastp);
   int cnt = 0;
-  // exit condition every wave reaches: done flag, or the hard bound on iterations
+  // exit condition every wave reaches: done flag (uniform), or the hard bound on iterations
   for (int it = 0; it < 4096 && !s.done; ++it) {
-    int a = ply_body<true>(L, g, lane, lab, lastp, s, m, P, b, b, 0ll);
-    if (moves && cnt < max_record && lane == 0) moves[(size_t)b * max_record + cnt] = (int16_t)a;
+    int a = ply_body<NW, true>(L, g, lab, lastp, s, m, o, P, b, 0ll);
+    gather_masks(L, g, o, m);
+    if (moves && cnt < max_record && g.tid == 0) moves[(size_t)b * max_record + cnt] = (int16_t)a;
     ++cnt;
   }
-  store_board(rec, g, lane, lab, lastp, m, s);
-  if (nmoves && lane == 0) nmoves[b] = cnt;
+  store_board(rec, g, lab, lastp, o, s);
+  if (nmoves && g.tid == 0) nmoves[b] = cnt;
 }
 
 // Replay of given move lists (SGF records packed on the host): row b applies
 // moves[b*stride + 0 .. nmoves[b]) to its board with GoState::forward semantics and stops at the
 // first illegal move (go/offpolicy_loader.cc:120-126); napplied[b] = moves applied.  The board
 // stays in LDS/registers for the whole list.
-__global__ __launch_bounds__(64) void k_replay(PlyParams P, const int16_t* moves, int stride, const int32_t* nmoves,
-                                               int32_t* napplied) {
-  __shared__ WaveLds L;
-  const int b = blockIdx.x, lane = threadIdx.x;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_replay(PlyParams P, const int16_t* moves, int stride,
+                                                    const int32_t* nmoves, int32_t* napplied) {
+  __shared__ BoardLds<NW> L;
+  const int b = blockIdx.x;
   if (b >= P.n) return;
+  Geo<NW> g;
+  geo_init(g);
+  constexpr int K = Geo<NW>::K;
   const int board = board_of(P.idx, P.first, P.n_total, b);
   if (board < 0) {
-    if (lane == 0 && napplied) napplied[b] = -1;
+    if (g.tid == 0 && napplied) napplied[b] = -1;
     return;
   }
-  Geo g;
-  geo_init(g, lane);
   BoardRec* rec = P.state + board;
   Scalars s;
   load_scalars(rec, s);
-  uint32_t lab[KCH], lastp[KCH];
+  uint32_t lab[K], lastp[K];
   Masks m;
+  Own<NW> o;
   load_masks(rec, m);
-  load_board(rec, L, g, lane, lab, lastp);
+  own_from_masks(g, m, o);
+  load_board(rec, L, g, lab, lastp);
   int n = nmoves[b];
   n = __builtin_amdgcn_readfirstlane(n < 0 ? 0 : (n > stride ? stride : n));
   int cnt = 0;
   for (; cnt < n; ++cnt) {  // bounded by the host-supplied list length
-    const int a = ply_body<false>(L, g, lane, lab, lastp, s, m, P, b, board, (long long)moves[(size_t)b * stride + cnt]);
+    const int a = ply_body<NW, false>(L, g, lab, lastp, s, m, o, P, board, (long long)moves[(size_t)b * stride + cnt]);
     if (a == -4) break;
+    gather_masks(L, g, o, m);
   }
-  if (cnt > 0) store_board(rec, g, lane, lab, lastp, m, s);
-  if (napplied && lane == 0) napplied[b] = cnt;
+  if (cnt > 0) store_board(rec, g, lab, lastp, o, s);
+  if (napplied && g.tid == 0) napplied[b] = cnt;
 }
+
+// Launch of a kernel template on the waves-per-board count chosen for this call.
+#define GO_LAUNCH(NWSEL, KERNEL, GRID, STREAM, ...)                                                  \
+  do {                                                                                               \
+    switch (NWSEL) {                                                                                 \
+      case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(GRID), dim3(128), 0, STREAM, __VA_ARGS__); break; \
+      case 3: hipLaunchKernelGGL((KERNEL<3>), dim3(GRID), dim3(192), 0, STREAM, __VA_ARGS__); break; \
+      case 6: hipLaunchKernelGGL((KERNEL<6>), dim3(GRID), dim3(384), 0, STREAM, __VA_ARGS__); break; \
+      default: hipLaunchKernelGGL((KERNEL<1>), dim3(GRID), dim3(64), 0, STREAM, __VA_ARGS__); break; \
+    }                                                                                                \
+  } while (0)
+
+#define GO_LAUNCH_PLY(NWSEL, RANDOM, GRID, STREAM, P)                                                      \
+  do {                                                                                                    \
+    if (RANDOM) {                                                                                         \
+      switch (NWSEL) {                                                                                    \
+        case 2: hipLaunchKernelGGL((k_ply<2, true>), dim3(GRID), dim3(128), 0, STREAM, P); break;         \
+        case 3: hipLaunchKernelGGL((k_ply<3, true>), dim3(GRID), dim3(192), 0, STREAM, P); break;         \
+        case 6: hipLaunchKernelGGL((k_ply<6, true>), dim3(GRID), dim3(384), 0, STREAM, P); break;         \
+        default: hipLaunchKernelGGL((k_ply<1, true>), dim3(GRID), dim3(64), 0, STREAM, P); break;         \
+      }                                                                                                   \
+    } else {                                                                                              \
+      switch (NWSEL) {                                                                                    \
+        case 2: hipLaunchKernelGGL((k_ply<2, false>), dim3(GRID), dim3(128), 0, STREAM, P); break;        \
+        case 3: hipLaunchKernelGGL((k_ply<3, false>), dim3(GRID), dim3(192), 0, STREAM, P); break;        \
+        case 6: hipLaunchKernelGGL((k_ply<6, false>), dim3(GRID), dim3(384), 0, STREAM, P); break;        \
+        default: hipLaunchKernelGGL((k_ply<1, false>), dim3(GRID), dim3(64), 0, STREAM, P); break;        \
+      }                                                                                                   \
+    }                                                                                                     \
+  } while (0)
 
 // ----------------------------------------------------------------------------------------------
 // host side
@@ -566,7 +658,40 @@ struct goenv_ctx {
   unsigned long long* stats;
   float* lut;
   hipEvent_t ev0, ev1;
+  int nw;  // waves per board: 0 = by batch size, else 1 / 2 / 3 / 6
+  int zero_first;  // -1 = by batch size, 0 / 1 pinned (GOENV_ZERO_FIRST, tuning only)
+  float lut1;
 };
+
+// The standalone feature kernel has no rules phase that staggers its waves' stores: mid-size
+// launches do best with one wave per board (8,192 boards: 60 us vs 70 us with three).
+static int pick_nw_features(const goenv_ctx* c, int count) {
+  if (c->nw) return c->nw;
+  if (count <= 512) return 6;
+  if (count <= 4096) return 3;
+  if (count <= 32768) return 1;
+  return 3;
+}
+
+// How the planes are stored: bit 0 = the 11 constant planes first (tuning knob, no gain
+// measured), bit 1 = write-through (`sc1`) plane stores.  Write-through pays for launches whose
+// whole output fits the caches (no end-of-kernel write-back of tens of MB: 13.2 -> 12.1 us at
+// 1,024 boards) and costs 1.5x on an HBM-sized stream, so it is used for small launches only.
+static int pick_zero_first(const goenv_ctx* c, int count) {
+  if (c->zero_first >= 0) return c->zero_first;
+  return count <= 1536 ? 2 : 0;
+}
+
+// Waves per board of a launch over `count` boards.  Small launches are bound by the dependent
+// chain of one board, which more waves per board shorten (1,024 boards: 17.4 us with one wave,
+// 13.2 us with three); large ones are HBM-bound and still gain a few percent from two or three
+// waves sharing the plane stores of a board.
+static int pick_nw(const goenv_ctx* c, int count) {
+  if (c->nw) return c->nw;   // measured: tools/tune_waves.py, profiles/r01_tune_waves.txt
+  if (count <= 512) return 6;
+  if (count <= 12288) return 3;
+  return 2;
+}
 
 static thread_local std::string g_err;
 
@@ -604,7 +729,12 @@ int goenv_create(int device, int n_boards, uint64_t seed, int64_t board_id_base,
   HIPCHK(hipSetDevice(device));
   goenv_ctx* c = new goenv_ctx();
   c->device = device; c->n = n_boards; c->seed = seed; c->id_base = board_id_base;
-  c->komi = komi; c->max_ply = max_ply;
+  c->komi = komi; c->max_ply = max_ply; c->nw = 0; c->zero_first = -1;
+  if (const char* e = getenv("GOENV_ZERO_FIRST")) c->zero_first = atoi(e) & 3;
+  if (const char* e = getenv("GOENV_WAVES_PER_BOARD")) {
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 3 || v == 6) c->nw = v;
+  }
   c->state = nullptr; c->stats = nullptr; c->lut = nullptr;
   hipError_t e;
   if ((e = hipMalloc((void**)&c->state, (size_t)n_boards * sizeof(BoardRec))) != hipSuccess ||
@@ -620,12 +750,13 @@ int goenv_create(int device, int n_boards, uint64_t seed, int64_t board_id_base,
   static float lut[HIST_LUT_N];
   for (int d = 0; d < HIST_LUT_N; ++d) lut[d] = (float)exp((double)(-d) / 10.0);
   lut[HIST_LUT_N - 1] = 0.f;  // ages >= 2047 plies: exp(-204.7) underflows float to 0
+  c->lut1 = lut[1];
   HIPCHK(hipMemcpy(c->lut, lut, sizeof(lut), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(c->stats, 0, GOENV_NUM_STATS * sizeof(unsigned long long)));
   HIPCHK(hipMemset(c->state, 0, (size_t)n_boards * sizeof(BoardRec)));
   HIPCHK(hipEventCreate(&c->ev0));
   HIPCHK(hipEventCreate(&c->ev1));
-  hipLaunchKernelGGL(k_reset, dim3(n_boards), dim3(64), 0, 0, c->state, n_boards, nullptr, n_boards, nullptr);
+  GO_LAUNCH(pick_nw(c, n_boards), k_reset, n_boards, 0, c->state, n_boards, nullptr, n_boards, nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipDeviceSynchronize());
   *out = c;
@@ -646,6 +777,14 @@ int goenv_destroy(goenv_ctx* c) {
 }
 
 int goenv_num_boards(const goenv_ctx* c) { return c ? c->n : 0; }
+
+int goenv_set_waves_per_board(goenv_ctx* c, int nw) {
+  if (!c) return fail("goenv_set_waves_per_board: ctx is NULL");
+  if (!(nw == 0 || nw == 1 || nw == 2 || nw == 3 || nw == 6))
+    return fail("goenv_set_waves_per_board: waves per board must be 0 (automatic), 1, 2, 3 or 6");
+  c->nw = nw;
+  return 0;
+}
 void* goenv_state_ptr(goenv_ctx* c) { return c ? (void*)c->state : nullptr; }
 
 int goenv_reset(goenv_ctx* c, const int32_t* idx, int n, const int32_t* handicap, void* stream) {
@@ -653,7 +792,7 @@ int goenv_reset(goenv_ctx* c, const int32_t* idx, int n, const int32_t* handicap
   const int cnt = idx ? n : c->n;
   if (cnt <= 0) return idx ? 0 : fail("goenv_reset: empty context");
   if (idx && n > c->n) return fail("goenv_reset: n exceeds the number of boards");
-  hipLaunchKernelGGL(k_reset, dim3(cnt), dim3(64), 0, S(stream), c->state, c->n, idx, cnt, handicap);
+  GO_LAUNCH(pick_nw(c, cnt), k_reset, cnt, S(stream), c->state, c->n, idx, cnt, handicap);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -661,8 +800,8 @@ int goenv_reset(goenv_ctx* c, const int32_t* idx, int n, const int32_t* handicap
 int goenv_get_state(goenv_ctx* c, uint8_t* color, int16_t* liberties, int16_t* stones, uint16_t* last_placed,
                     int32_t* scalars, void* stream) {
   if (!c) return fail("goenv_get_state: ctx is NULL");
-  hipLaunchKernelGGL(k_get_state, dim3(c->n), dim3(64), 0, S(stream), c->state, c->n, nullptr, 0, c->n, color,
-                     liberties, stones, last_placed, scalars);
+  GO_LAUNCH(pick_nw(c, c->n), k_get_state, c->n, S(stream), c->state, c->n, nullptr, 0, c->n, color, liberties, stones,
+            last_placed, scalars);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -671,7 +810,7 @@ int goenv_set_state(goenv_ctx* c, const uint8_t* color, const uint16_t* last_pla
                     void* stream) {
   if (!c) return fail("goenv_set_state: ctx is NULL");
   if (!color || !scalars) return fail("goenv_set_state: color and scalars are required");
-  hipLaunchKernelGGL(k_set_state, dim3(c->n), dim3(64), 0, S(stream), c->state, c->n, color, last_placed, scalars);
+  GO_LAUNCH(pick_nw(c, c->n), k_set_state, c->n, S(stream), c->state, c->n, color, last_placed, scalars);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -685,6 +824,8 @@ static PlyParams make_params(goenv_ctx* c, uint32_t flags, const int64_t* action
   P.legal = legal; P.actions_out = actions_out; P.status = status; P.stats = c->stats; P.lut = c->lut;
   P.seed = c->seed; P.id_base = c->id_base; P.komi = c->komi; P.max_ply = c->max_ply;
   P.stamps = nullptr;
+  P.lut1 = c->lut1;
+  P.zero_first = pick_zero_first(c, c->n);
   return P;
 }
 
@@ -705,9 +846,9 @@ int goenv_ply_sel(goenv_ctx* c, const int32_t* idx, int first, int count, uint32
   if (count == 0) return 0;
   PlyParams P = make_params(c, flags, actions, aug_codes, feat_out, legal_out, actions_out, status_out);
   P.n = count; P.idx = idx; P.first = first;
+  P.zero_first = pick_zero_first(c, count);
   if (meta) P.meta = *meta;
-  if (random) hipLaunchKernelGGL(k_ply<true>, dim3(count), dim3(64), 0, S(stream), P);
-  else hipLaunchKernelGGL(k_ply<false>, dim3(count), dim3(64), 0, S(stream), P);
+  GO_LAUNCH_PLY(pick_nw(c, count), random, count, S(stream), P);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -726,7 +867,7 @@ extern "C" int goenv_diag_ply(goenv_ctx* c, uint32_t flags, float* feat_out, uin
                               unsigned long long* stamps, void* stream) {
   PlyParams P = make_params(c, flags | GOENV_F_RANDOM_POLICY, nullptr, nullptr, feat_out, legal_out, nullptr, nullptr);
   P.stamps = stamps;
-  hipLaunchKernelGGL(k_ply<true>, dim3(c->n), dim3(64), 0, S(stream), P);
+  GO_LAUNCH_PLY(pick_nw(c, c->n), true, c->n, S(stream), P);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -743,8 +884,8 @@ int goenv_collect_sel(goenv_ctx* c, const int32_t* idx, int first, int count, co
   goenv_sample_out m;
   memset(&m, 0, sizeof(m));
   if (meta) m = *meta;
-  hipLaunchKernelGGL(k_features, dim3(count), dim3(64), 0, S(stream), c->state, c->n, idx, first, count, aug_codes,
-                     c->lut, feat_out, legal_out, m, meta ? 1 : 0);
+  GO_LAUNCH(pick_nw_features(c, count), k_features, count, S(stream), c->state, c->n, idx, first, count, aug_codes, c->lut,
+            feat_out, legal_out, m, meta ? 1 : 0, c->lut1, pick_zero_first(c, count));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -802,8 +943,8 @@ int goenv_get_state_sel(goenv_ctx* c, const int32_t* idx, int first, int count, 
                         int16_t* stones, uint16_t* last_placed, int32_t* scalars, void* stream) {
   if (check_sel(c, idx, first, count, "goenv_get_state_sel")) return -1;
   if (count == 0) return 0;
-  hipLaunchKernelGGL(k_get_state, dim3(count), dim3(64), 0, S(stream), c->state, c->n, idx, first, count, color,
-                     liberties, stones, last_placed, scalars);
+  GO_LAUNCH(pick_nw(c, count), k_get_state, count, S(stream), c->state, c->n, idx, first, count, color, liberties,
+            stones, last_placed, scalars);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -816,7 +957,7 @@ int goenv_replay(goenv_ctx* c, const int32_t* idx, int first, int count, const i
   PlyParams P = make_params(c, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   P.n = count; P.idx = idx; P.first = first;
   P.max_ply = 0;  // a replayed record is not subject to the playout ply cap
-  hipLaunchKernelGGL(k_replay, dim3(count), dim3(64), 0, S(stream), P, moves, stride, nmoves, napplied_out);
+  GO_LAUNCH(pick_nw(c, count), k_replay, count, S(stream), P, moves, stride, nmoves, napplied_out);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -837,21 +978,21 @@ int goenv_playout(goenv_ctx* c, int16_t* moves_out, int max_record, int32_t* nmo
   if (c->max_ply <= 0) return fail("goenv_playout: the context needs a ply cap (max_ply > 0)");
   if (moves_out && max_record <= 0) return fail("goenv_playout: max_record must be positive");
   PlyParams P = make_params(c, GOENV_F_RANDOM_POLICY, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-  hipLaunchKernelGGL(k_playout, dim3(c->n), dim3(64), 0, S(stream), P, moves_out, max_record, nmoves_out);
+  GO_LAUNCH(pick_nw(c, c->n), k_playout, c->n, S(stream), P, moves_out, max_record, nmoves_out);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 int goenv_score(goenv_ctx* c, float* score_out, float* fast_out, void* stream) {
   if (!c) return fail("goenv_score: ctx is NULL");
-  hipLaunchKernelGGL(k_score, dim3(c->n), dim3(64), 0, S(stream), c->state, c->n, score_out, fast_out);
+  GO_LAUNCH(pick_nw(c, c->n), k_score, c->n, S(stream), c->state, c->n, score_out, fast_out);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 int goenv_finish(goenv_ctx* c, void* stream) {
   if (!c) return fail("goenv_finish: ctx is NULL");
-  hipLaunchKernelGGL(k_finish, dim3(c->n), dim3(64), 0, S(stream), c->state, c->n, c->stats, c->komi);
+  GO_LAUNCH(pick_nw(c, c->n), k_finish, c->n, S(stream), c->state, c->n, c->stats, c->komi);
   HIPCHK(hipGetLastError());
   return 0;
 }

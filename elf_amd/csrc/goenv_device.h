@@ -1,30 +1,34 @@
-// goenv_device.h -- wave-per-board device code of the gfx950 Go environment.
+// goenv_device.h -- device code of the gfx950 Go environment: one workgroup of NW wavefronts
+// (NW in {1,2,3,6}) owns one 19x19 board.
 //
-// One 64-lane wavefront owns one 19x19 board.  Lane l handles the points
-// p = l + 64*k, k = 0..5 (p = x*19 + y, the reference's export order,
-// go/board.h:155), so every batch-buffer store is lane-contiguous.  Neighbour
-// lookups go through a 21x21 padded label image in LDS (index c = (x+1)*21 +
-// (y+1)) whose rim is a sentinel colour -- the same trick as the reference's
-// 21x21 `_infos` (go/board.h:80) -- so no edge tests are needed.
+// Thread t of the workgroup handles the points p = t + 64*NW*k, k = 0..K-1 with K = 6/NW
+// (p = x*19 + y, the reference's export order, go/board.h:155), so every batch-buffer store is
+// lane-contiguous and the ballot of chunk k taken by wave w is word NW*k + w of the board's
+// 361-bit mask (bit p%64 of word p/64).  NW = 1 is "one wavefront per board": everything is
+// wave-local.  NW > 1 splits the per-point work of one board over several waves -- at small
+// batches (1,024 boards on 256 CUs) the chip is latency-bound with one wave per SIMD, and several
+// waves per board cut the dependent LDS/VALU chain per wave by that factor; the few values that
+// are properties of the whole board (capture count, colour masks) cross waves through LDS.
 //
-// State model (differs from the reference on purpose): every stone carries the
-// 13-bit label  root | colour<<9 | cls<<11  where root is the point index of the
-// most recently added stone of its group and cls = min(liberties of the group, 3).
-// * Merging groups and removing captured groups are single lane-parallel relabel
-//   passes (replacing the linked-list walks of MergeGroups/EmptyGroup,
-//   go/board.cc:559-593,412-434).
-// * The liberty table lib[root] is rebuilt from scratch each ply: every empty
-//   point adds 1 to each distinct neighbouring root with LDS atomics (replacing
-//   the incremental bookkeeping of go/board.cc:393-409,529-555,595-620).  The
-//   reference's stored liberties always equal this from-scratch count
-//   (VerifyBoard, go/board.cc:1455-1462), so the two models are observably
+// Neighbour lookups go through a 21x21 padded label image in LDS (index c = (x+1)*21 + (y+1))
+// whose rim is a sentinel colour -- the same trick as the reference's 21x21 `_infos`
+// (go/board.h:80) -- so no edge tests are needed.
+//
+// State model (differs from the reference on purpose): every stone carries the 13-bit label
+// root | colour<<9 | cls<<11  where root is the point index of the most recently added stone of
+// its group and cls = min(liberties of the group, 3).
+// * Merging groups and removing captured groups are single thread-parallel relabel passes
+//   (replacing the linked-list walks of MergeGroups/EmptyGroup, go/board.cc:559-593,412-434).
+// * The liberty table lib[root] is rebuilt from scratch each ply: every empty point adds 1 to
+//   each distinct neighbouring root with LDS atomics (replacing the incremental bookkeeping of
+//   go/board.cc:393-409,529-555,595-620).  The reference's stored liberties always equal this
+//   from-scratch count (VerifyBoard, go/board.cc:1455-1462), so the two models are observably
 //   identical.
-// * Because every neighbour read returns colour AND liberty class, legality,
-//   eye and feature tests are branch-free table lookups on one LDS read per
-//   neighbour (no dependent group-table gather as in StoneLibertyAnalysis,
-//   go/board.cc:95-129).
-// * The legal mask and the playout-candidate mask of the side to move are
-//   computed once per ply and kept in the record as 2 x 361-bit ballots.
+// * Because every neighbour read returns colour AND liberty class, legality, eye and feature
+//   tests are branch-free table lookups on one LDS read per neighbour (no dependent group-table
+//   gather as in StoneLibertyAnalysis, go/board.cc:95-129).
+// * The legal mask and the playout-candidate mask of the side to move are computed once per ply
+//   and kept in the record as 2 x 361-bit ballots.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -35,10 +39,9 @@ namespace goenv {
 constexpr int BS = 19;
 constexpr int NPTS = 361;
 constexpr int PW = 21;       // padded width
-constexpr int KCH = 6;       // 64-lane chunks covering 361 points
+constexpr int NWORDS = 6;    // 64-bit words covering 361 points
 constexpr int LAB_N = 448;   // padded label image entries (441 used)
 constexpr int TAB_N = 368;   // per-point tables, 361 rounded up
-constexpr int LIB_N = TAB_N + 64;  // + one atomic sink slot per lane
 constexpr int HIST_LUT_N = 2048;
 
 constexpr int S_EMPTY = 0, S_BLACK = 1, S_WHITE = 2;
@@ -51,51 +54,79 @@ constexpr int DIST_INF = 64;
 enum { SC_PLY = 0, SC_NEXT, SC_BCAP, SC_WCAP, SC_L1, SC_L2, SC_L3, SC_L4, SC_KOAGE, SC_KO,
        SC_KOCOLOR, SC_DONE, SC_GAME, SC_COUNTED, SC_SEQ, SC_SEQTOT };
 
-// Packed per-board record in HBM: 1632 B, 16-B aligned, one contiguous read per wave.
+// Packed per-board record in HBM: 1632 B, 16-B aligned, one contiguous read per workgroup.
 struct __attribute__((aligned(16))) BoardRec {
   uint16_t lab[TAB_N];    // root | colour<<9 | cls<<11, 0 = empty       (export order)
   uint16_t lastp[TAB_N];  // ply of placement (go/board.h:46); stale under empties
-  uint64_t legal[KCH];    // FindAllValidMoves of the side to move, bit p%64 of word p/64
-  uint64_t cand[KCH];     // legal AND NOT own true eye (cfg-2 playout policy)
+  uint64_t legal[NWORDS]; // FindAllValidMoves of the side to move, bit p%64 of word p/64
+  uint64_t cand[NWORDS];  // legal AND NOT own true eye (cfg-2 playout policy)
   int32_t sc[16];
 };
 static_assert(sizeof(BoardRec) == 1632, "record layout");
 
-// Per-wave LDS working set (~4.9 KB -> 32 waves/CU fit in 160 KB).
-struct WaveLds {
-  uint32_t lib[LIB_N];      // liberties by root (+ per-lane sink slots for masked atomics)
-  uint32_t desc[TAB_N];     // per-point feature descriptor; also flood-fill scratch
-  uint16_t lab[LAB_N];      // padded label image
-  uint8_t dist[2][TAB_N];   // L1 distance to nearest black / white stone
+// Per-board LDS working set (~5 KB -> 32 single-wave boards per CU fit in 160 KB).
+template <int NW>
+struct BoardLds {
+  uint32_t lib[TAB_N + 64 * NW];  // liberties by root (+ one sink slot per thread for masked atomics)
+  uint32_t desc[TAB_N];           // per-point feature descriptor; also flood-fill scratch
+  uint16_t lab[LAB_N];            // padded label image
+  uint8_t dist[2][TAB_N];         // L1 distance to nearest black / white stone
+  // cross-wave exchange (unused when NW == 1)
+  unsigned long long xcol[2 * NWORDS];   // colour ballots
+  unsigned long long xmask[2 * NWORDS];  // legal / candidate ballots
+  uint32_t xcap[8];                      // per-wave capture count | (point+1) << 16
+  int32_t xsum[2][8];                    // per-wave partial sums
+  uint32_t xflag[4];                     // "something changed" flags of fixed-point loops
 };
 
 struct Scalars {
   int ply, next, bcap, wcap, l1, l2, l3, l4, koage, ko, kocolor, done, game, counted, seq, seqtot;
 };
 
-struct Geo {
-  int p[KCH];  // point index (may be >= 361 in the last chunk)
-  int c[KCH];  // padded index; an interior cell (never written) for invalid lanes
+struct Masks {  // all six words, uniform
+  unsigned long long legal[NWORDS];
+  unsigned long long cand[NWORDS];
 };
 
-struct Masks {
-  unsigned long long legal[KCH];
-  unsigned long long cand[KCH];
+template <int NW>
+struct Own {  // the K words of each mask that this wave's ballots produce (word NW*k + wave)
+  unsigned long long legal[NWORDS / NW];
+  unsigned long long cand[NWORDS / NW];
+  unsigned long long eye[NWORDS / NW];
+};
+
+template <int NW>
+struct Geo {
+  static constexpr int K = NWORDS / NW;
+  static constexpr int T = 64 * NW;
+  int tid, lane, wave;
+  int p[K];  // point index (may be >= 361 in the last chunk)
+  int c[K];  // padded index; an interior cell (never written) for invalid threads
 };
 
 #define GO_UNROLL _Pragma("unroll")
-#define WSYNC() __syncthreads()  // block == one wave: lowers to a wave-level fence
+#define WSYNC() __syncthreads()  // NW == 1: lowers to a wave-level fence
 
 __device__ __forceinline__ int popc64(unsigned long long v) { return __popcll(v); }
 __device__ __forceinline__ uint32_t col_of(uint32_t v) { return (v >> 9) & 3u; }
 __device__ __forceinline__ uint32_t cls_of(uint32_t v) { return (v >> 11) & 3u; }
 __device__ __forceinline__ uint32_t typ_of(uint32_t v) { return (v >> 9) & 15u; }  // colour | cls<<2
 
-__device__ __forceinline__ void geo_init(Geo& g, int lane) {
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int NW>
+__device__ __forceinline__ void geo_init(Geo<NW>& g) {
+  g.tid = threadIdx.x;
+  g.lane = g.tid & 63;
+  g.wave = __builtin_amdgcn_readfirstlane(g.tid >> 6);
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
-    int p = lane + 64 * k;
-    int x = p / BS, y = p - x * BS;
+  for (int k = 0; k < Geo<NW>::K; ++k) {
+    const int p = g.tid + Geo<NW>::T * k;
+    const int x = p / BS, y = p - x * BS;
     g.p[k] = p;
     g.c[k] = (p < NPTS) ? (x + 1) * PW + (y + 1) : PW + 1;
   }
@@ -115,10 +146,10 @@ __device__ __forceinline__ void load_scalars(const BoardRec* rec, Scalars& s) {
   s.seqtot = sc[SC_SEQTOT];
 }
 
-__device__ __forceinline__ void store_scalars(BoardRec* rec, const Scalars& s, int lane) {
-  // one 64-B line, written by 16 lanes
+__device__ __forceinline__ void store_scalars(BoardRec* rec, const Scalars& s, int tid) {
+  // one 64-B line, written by the first 16 threads
   int v = 0;
-  switch (lane) {
+  switch (tid) {
     case SC_PLY: v = s.ply; break;       case SC_NEXT: v = s.next; break;
     case SC_BCAP: v = s.bcap; break;     case SC_WCAP: v = s.wcap; break;
     case SC_L1: v = s.l1; break;         case SC_L2: v = s.l2; break;
@@ -129,7 +160,7 @@ __device__ __forceinline__ void store_scalars(BoardRec* rec, const Scalars& s, i
     case SC_SEQ: v = s.seq; break;       case SC_SEQTOT: v = s.seqtot; break;
     default: v = 0;
   }
-  if (lane < 16) rec->sc[lane] = v;
+  if (tid < 16) rec->sc[tid] = v;
 }
 
 // ClearBoard, go/board.cc:30-46 (scalars only; the caller zeroes the tables)
@@ -139,76 +170,157 @@ __device__ __forceinline__ void clear_scalars(Scalars& s) {
   s.koage = 0; s.ko = -1; s.kocolor = 0; s.done = 0; s.counted = 0; s.seq = 0;
 }
 
-__device__ __forceinline__ void fill_rim(WaveLds& L, int lane) {
-  for (int i = lane; i < LAB_N; i += 64) L.lab[i] = (uint16_t)BORDER;
+template <int NW>
+__device__ __forceinline__ void fill_rim(BoardLds<NW>& L, int tid) {
+  for (int i = tid; i < LAB_N; i += 64 * NW) L.lab[i] = (uint16_t)BORDER;
 }
 
 // HBM record -> LDS image + registers.
-__device__ __forceinline__ void load_board(const BoardRec* rec, WaveLds& L, const Geo& g, int lane,
-                                           uint32_t lab[KCH], uint32_t lastp[KCH]) {
+template <int NW>
+__device__ __forceinline__ void load_board(const BoardRec* rec, BoardLds<NW>& L, const Geo<NW>& g,
+                                           uint32_t lab[], uint32_t lastp[]) {
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
+  for (int k = 0; k < Geo<NW>::K; ++k) {
     bool v = g.p[k] < NPTS;
     lab[k] = v ? rec->lab[g.p[k]] : 0u;
     lastp[k] = v ? rec->lastp[g.p[k]] : 0u;
   }
-  fill_rim(L, lane);
+  fill_rim(L, g.tid);
   WSYNC();
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k)
+  for (int k = 0; k < Geo<NW>::K; ++k)
     if (g.p[k] < NPTS) L.lab[g.c[k]] = (uint16_t)lab[k];
   WSYNC();
 }
 
 __device__ __forceinline__ void load_masks(const BoardRec* rec, Masks& m) {
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) { m.legal[k] = rec->legal[k]; m.cand[k] = rec->cand[k]; }
+  for (int j = 0; j < NWORDS; ++j) { m.legal[j] = rec->legal[j]; m.cand[j] = rec->cand[j]; }
 }
 
-__device__ __forceinline__ void clear_board_lds(WaveLds& L, const Geo& g, int lane, uint32_t lab[KCH],
-                                                uint32_t lastp[KCH]) {
-  fill_rim(L, lane);
+// this wave's words of the uniform six-word masks
+template <int NW>
+__device__ __forceinline__ void own_from_masks(const Geo<NW>& g, const Masks& m, Own<NW>& o) {
+  GO_UNROLL
+  for (int k = 0; k < Geo<NW>::K; ++k) {
+    unsigned long long wl = 0, wc = 0;
+    GO_UNROLL
+    for (int j = 0; j < NWORDS; ++j)
+      if (j == NW * k + g.wave) { wl = m.legal[j]; wc = m.cand[j]; }
+    o.legal[k] = wl; o.cand[k] = wc; o.eye[k] = wl & ~wc;
+  }
+}
+
+template <int NW>
+__device__ __forceinline__ void clear_board_lds(BoardLds<NW>& L, const Geo<NW>& g, uint32_t lab[], uint32_t lastp[]) {
+  fill_rim(L, g.tid);
   WSYNC();
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
+  for (int k = 0; k < Geo<NW>::K; ++k) {
     lab[k] = 0; lastp[k] = 0;
     if (g.p[k] < NPTS) L.lab[g.c[k]] = 0;
   }
   WSYNC();
 }
 
+__device__ __forceinline__ unsigned long long full_word(int j) {
+  return (j < NWORDS - 1) ? ~0ull : ((1ull << (NPTS - 64 * (NWORDS - 1))) - 1ull);
+}
+
 // masks of an empty board with BLACK to move: every point legal and a candidate
-__device__ __forceinline__ void full_masks(Masks& m) {
+template <int NW>
+__device__ __forceinline__ void full_masks(const Geo<NW>& g, Masks& m, Own<NW>& o) {
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
-    unsigned long long w = (k < KCH - 1) ? ~0ull : ((1ull << (NPTS - 64 * (KCH - 1))) - 1ull);
-    m.legal[k] = w; m.cand[k] = w;
+  for (int j = 0; j < NWORDS; ++j) { m.legal[j] = full_word(j); m.cand[j] = full_word(j); }
+  own_from_masks(g, m, o);
+}
+
+// Each wave's own words -> all six words in every wave (through LDS when NW > 1).
+template <int NW>
+__device__ __forceinline__ void gather_masks(BoardLds<NW>& L, const Geo<NW>& g, const Own<NW>& o, Masks& m) {
+  if (NW == 1) {
+    GO_UNROLL
+    for (int j = 0; j < NWORDS / NW; ++j) { m.legal[j] = o.legal[j]; m.cand[j] = o.cand[j]; }
+    return;
+  }
+  if (g.lane == 0) {
+    GO_UNROLL
+    for (int k = 0; k < Geo<NW>::K; ++k) {
+      L.xmask[NW * k + g.wave] = o.legal[k];
+      L.xmask[NWORDS + NW * k + g.wave] = o.cand[k];
+    }
+  }
+  WSYNC();
+  GO_UNROLL
+  for (int j = 0; j < NWORDS; ++j) { m.legal[j] = uni64(L.xmask[j]); m.cand[j] = uni64(L.xmask[NWORDS + j]); }
+  WSYNC();  // the array may be rewritten right after
+}
+
+// Sum of a wave-uniform value over the waves of the board.
+template <int NW>
+__device__ __forceinline__ int board_sum(BoardLds<NW>& L, const Geo<NW>& g, int v, int slot) {
+  if (NW == 1) return v;
+  if (g.lane == 0) L.xsum[slot][g.wave] = v;
+  WSYNC();
+  int s = 0;
+  GO_UNROLL
+  for (int w = 0; w < NW; ++w) s += L.xsum[slot][w];
+  s = __builtin_amdgcn_readfirstlane(s);
+  WSYNC();
+  return s;
+}
+
+// "did any thread of the board change something" inside a fixed-point loop; three rotating flag
+// words so that clearing never races with a late reader.  Contains the loop's barrier.
+template <int NW>
+__device__ __forceinline__ bool board_any(BoardLds<NW>& L, const Geo<NW>& g, bool changed, int iter) {
+  if (NW == 1) {
+    WSYNC();
+    return __any(changed);
+  }
+  const int cur = iter % 3, nxt = (iter + 1) % 3;
+  if (g.tid == 0) L.xflag[nxt] = 0;
+  if (__any(changed) && g.lane == 0) L.xflag[cur] = 1;
+  WSYNC();
+  return __builtin_amdgcn_readfirstlane(L.xflag[cur]) != 0;
+}
+
+template <int NW>
+__device__ __forceinline__ void board_any_init(BoardLds<NW>& L, const Geo<NW>& g) {
+  if (NW > 1) {
+    if (g.tid < 3) L.xflag[g.tid] = 0;
+    WSYNC();
   }
 }
 
-__device__ __forceinline__ void store_board(BoardRec* rec, const Geo& g, int lane, const uint32_t lab[KCH],
-                                            const uint32_t lastp[KCH], const Masks& m, const Scalars& s) {
+template <int NW>
+__device__ __forceinline__ void store_board(BoardRec* rec, const Geo<NW>& g, const uint32_t lab[],
+                                            const uint32_t lastp[], const Own<NW>& o, const Scalars& s) {
+  constexpr int K = Geo<NW>::K;
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
+  for (int k = 0; k < K; ++k) {
     if (g.p[k] < NPTS) {
       rec->lab[g.p[k]] = (uint16_t)lab[k];
       rec->lastp[g.p[k]] = (uint16_t)lastp[k];
     }
   }
-  // 12 mask words, one lane each
+  // this wave's mask words: lane k writes the legal word, lane K + k the candidate word
   unsigned long long w = 0;
+  int j = 0;
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
-    if (lane == k) w = m.legal[k];
-    if (lane == KCH + k) w = m.cand[k];
+  for (int k = 0; k < K; ++k) {
+    if (g.lane == k) { w = o.legal[k]; j = NW * k + g.wave; }
+    if (g.lane == K + k) { w = o.cand[k]; j = NWORDS + NW * k + g.wave; }
   }
-  if (lane < 2 * KCH) rec->legal[lane] = w;  // legal[6] and cand[6] are contiguous
-  store_scalars(rec, s, lane);
+  uint64_t* words = rec->legal;  // legal[6] and cand[6] are contiguous
+  if (g.lane < 2 * K) words[j] = w;
+  store_scalars(rec, s, g.tid);
 }
 
 // 4 neighbours of padded index c in the reference's L,T,R,B order (go/board.h:183):
 // x-1, y-1, x+1, y+1.
-__device__ __forceinline__ void nbr4(const WaveLds& L, int c, uint32_t n[4]) {
+template <int NW>
+__device__ __forceinline__ void nbr4(const BoardLds<NW>& L, int c, uint32_t n[4]) {
   n[0] = L.lab[c - PW];
   n[1] = L.lab[c - 1];
   n[2] = L.lab[c + PW];
@@ -220,15 +332,16 @@ __device__ __forceinline__ bool is_stone(uint32_t v) { uint32_t c = col_of(v); r
 // Liberty table from scratch: every empty point adds 1 to each DISTINCT neighbouring root
 // (== the distinct-liberty count RecomputeGroupLiberties produces, go/board.cc:595-620), then
 // every stone's cls bits are refreshed to min(liberties, 3).  Branch-free: masked-off adds go to
-// a per-lane sink slot.
-__device__ __forceinline__ void rebuild_lib(WaveLds& L, const Geo& g, int lane, uint32_t lab[KCH]) {
+// a per-thread sink slot.
+template <int NW>
+__device__ __forceinline__ void rebuild_lib(BoardLds<NW>& L, const Geo<NW>& g, uint32_t lab[]) {
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k)
+  for (int k = 0; k < Geo<NW>::K; ++k)
     if (g.p[k] < NPTS) L.lib[g.p[k]] = 0;
   WSYNC();
-  const int sink = TAB_N + lane;
+  const int sink = TAB_N + g.tid;
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
+  for (int k = 0; k < Geo<NW>::K; ++k) {
     if (g.p[k] < NPTS && lab[k] == 0) {
       uint32_t n[4];
       nbr4(L, g.c[k], n);
@@ -247,7 +360,7 @@ __device__ __forceinline__ void rebuild_lib(WaveLds& L, const Geo& g, int lane, 
   }
   WSYNC();
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
+  for (int k = 0; k < Geo<NW>::K; ++k) {
     if (g.p[k] < NPTS && lab[k] != 0) {
       uint32_t lib = L.lib[lab[k] & ROOT_MASK];
       uint32_t v = (lab[k] & LABEL_MASK) | ((lib > 3u ? 3u : lib) << 11);
@@ -275,17 +388,18 @@ __device__ __forceinline__ uint32_t tab_col(uint32_t colour) {  // any cls
 }
 
 // Legal mask (FindAllValidMoves, go/board.cc:763-779: empty, not a simple-ko violation :156-161,
-// not suicide :131-154) and own-true-eye mask (IsTrueEye :1501-1552) for `player`, as ballots.
-__device__ __forceinline__ void move_masks(const WaveLds& L, const Geo& g, const uint32_t lab[KCH],
-                                           const Scalars& s, int player, Masks& m,
-                                           unsigned long long eye_w[KCH]) {
+// not suicide :131-154) and own-true-eye mask (IsTrueEye :1501-1552) for `player`, as this wave's
+// ballot words.
+template <int NW>
+__device__ __forceinline__ void move_masks(const BoardLds<NW>& L, const Geo<NW>& g, const uint32_t lab[],
+                                           const Scalars& s, int player, Own<NW>& o) {
   const uint32_t OK = tab_ok(player);
   const uint32_t OWNR = tab_col((uint32_t)player) | tab_col(3u);
   const uint32_t OPP = tab_col(3u - (uint32_t)player);
   const uint32_t RIM = tab_col(3u);
   const int ko_p = (s.koage == 0 && s.kocolor == player) ? s.ko : -1;
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
+  for (int k = 0; k < Geo<NW>::K; ++k) {
     const int c = g.c[k];
     uint32_t n[4];
     nbr4(L, c, n);
@@ -300,9 +414,9 @@ __device__ __forceinline__ void move_masks(const WaveLds& L, const Geo& g, const
     const bool fake = n_rim > 0 ? n_opp >= 1 : n_opp >= 2;  // IsFakeEye go/board.cc:1530-1544
     const bool legal = empty && ok && g.p[k] != ko_p;
     const bool eye = empty && all_own && !fake;
-    m.legal[k] = __ballot(legal);
-    eye_w[k] = __ballot(eye);
-    m.cand[k] = m.legal[k] & ~eye_w[k];
+    o.legal[k] = __ballot(legal);
+    o.eye[k] = __ballot(eye);
+    o.cand[k] = o.legal[k] & ~o.eye[k];
   }
 }
 
@@ -319,9 +433,10 @@ __device__ __forceinline__ bool game_end(const Scalars& s) {
 }
 
 // Legality of one board move for `player` from the image (TryPlay, go/board.cc:626-662).
-// Wave-uniform.  Used where the stored masks do not apply (handicap stones are BLACK's
-// whoever is to move).
-__device__ __forceinline__ bool move_is_legal(const WaveLds& L, const Scalars& s, int p, int player) {
+// Uniform.  Used where the stored masks do not apply (handicap stones are BLACK's whoever is
+// to move).
+template <int NW>
+__device__ __forceinline__ bool move_is_legal(const BoardLds<NW>& L, const Scalars& s, int p, int player) {
   const int c = pad_of(p);
   if (L.lab[c] != 0) return false;
   if (s.ko == p && s.koage == 0 && s.kocolor == player) return false;
@@ -333,8 +448,9 @@ __device__ __forceinline__ bool move_is_legal(const WaveLds& L, const Scalars& s
 
 // Play (go/board.cc:1083-1179) of a LEGAL board move p for `player`; leaves the liberty table and
 // cls bits rebuilt.
-__device__ __forceinline__ void apply_move(WaveLds& L, const Geo& g, int lane, uint32_t lab[KCH],
-                                           uint32_t lastp[KCH], Scalars& s, int p, int player) {
+template <int NW>
+__device__ __forceinline__ void apply_move(BoardLds<NW>& L, const Geo<NW>& g, uint32_t lab[], uint32_t lastp[],
+                                           Scalars& s, int p, int player) {
   const int c = pad_of(p);
   const uint32_t opp = 3u - (uint32_t)player;
   uint32_t n[4];
@@ -351,10 +467,11 @@ __device__ __forceinline__ void apply_move(WaveLds& L, const Geo& g, int lane, u
     dead[i] = __builtin_amdgcn_readfirstlane((col == opp && cls_of(n[i]) == 1) ? r : -1);
     merged |= own[i] >= 0;
   }
+  if (NW > 1) WSYNC();  // every wave has read the neighbourhood before any wave rewrites it
   const uint32_t nv = ((uint32_t)player << 9) | (uint32_t)p;
   int total_capture = 0, capture_p = -1;
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
+  for (int k = 0; k < Geo<NW>::K; ++k) {
     uint32_t v = lab[k];
     const int r = (int)(v & ROOT_MASK);
     const uint32_t col = col_of(v);
@@ -364,12 +481,22 @@ __device__ __forceinline__ void apply_move(WaveLds& L, const Geo& g, int lane, u
     if (cap) v = 0;
     if (g.p[k] == p) { v = nv; lastp[k] = (uint32_t)s.ply & 0xffffu; }  // board.cc:532,1157
     const unsigned long long m = __ballot(cap);
-    if (m) { total_capture += popc64(m); capture_p = 64 * k + (int)__builtin_ctzll(m); }
+    if (m) { total_capture += popc64(m); capture_p = 64 * (NW * k + g.wave) + (int)__builtin_ctzll(m); }
     if (v != lab[k]) { L.lab[g.c[k]] = (uint16_t)v; lab[k] = v; }
   }
-  if (player == S_BLACK) s.bcap += total_capture; else s.wcap += total_capture;  // board.cc:1132-1133
+  if (NW > 1 && g.lane == 0) L.xcap[g.wave] = (uint32_t)total_capture | ((uint32_t)(capture_p + 1) << 16);
   WSYNC();
-  rebuild_lib(L, g, lane, lab);
+  if (NW > 1) {
+    total_capture = 0; capture_p = -1;
+    GO_UNROLL
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t v = __builtin_amdgcn_readfirstlane(L.xcap[w]);
+      total_capture += (int)(v & 0xffffu);
+      if (v & 0xffffu) capture_p = (int)(v >> 16) - 1;
+    }
+  }
+  if (player == S_BLACK) s.bcap += total_capture; else s.wcap += total_capture;  // board.cc:1132-1133
+  rebuild_lib(L, g, lab);
   // simple ko, board.cc:1163-1171
   if (!merged && total_capture == 1 && L.lib[p] == 1) {
     s.ko = capture_p; s.kocolor = (int)opp; s.koage = 0;
@@ -393,25 +520,25 @@ __device__ __forceinline__ uint64_t policy_rand(uint64_t seed, uint64_t board_id
 }
 
 // cfg-2 policy: uniform over the candidate ballots (legal AND NOT own true eye), pass if none.
-// Wave-uniform result.
+// Works on the uniform six-word mask, so every wave computes the same result by itself.
 __device__ __forceinline__ int pick_random_move(const Masks& m, int lane, const Scalars& s, uint64_t seed,
                                                 uint64_t board_id) {
   int n = 0;
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) n += popc64(m.cand[k]);
+  for (int j = 0; j < NWORDS; ++j) n += popc64(m.cand[j]);
   if (n == 0) return -1;
   const uint64_t u = policy_rand(seed, board_id, (uint64_t)s.game, (uint64_t)s.ply);
   int idx = (int)(((u >> 32) * (uint64_t)n) >> 32);
   int chosen = -1;
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
-    const unsigned long long w = m.cand[k];
+  for (int j = 0; j < NWORDS; ++j) {
+    const unsigned long long w = m.cand[j];
     const int cnt = popc64(w);
     if (chosen < 0) {
       if (idx < cnt) {
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(w >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)w, 0u));
         const unsigned long long hit = __ballot(((w >> lane) & 1ull) && rank == idx);
-        chosen = 64 * k + (int)__builtin_ctzll(hit);
+        chosen = 64 * j + (int)__builtin_ctzll(hit);
       } else {
         idx -= cnt;
       }
@@ -423,13 +550,16 @@ __device__ __forceinline__ int pick_random_move(const Masks& m, int lane, const 
 // GetTrompTaylorScore(board, NULL, NULL), go/board.cc:1584-1688: stones plus empty regions
 // that touch exactly one colour; 0 on an empty board.  Monotone OR-propagation of
 // "touches black / touches white" bits over the empties, in place, until a fixed point.
-__device__ __forceinline__ int tromp_taylor(WaveLds& L, const Geo& g, int lane, const uint32_t lab[KCH]) {
+template <int NW>
+__device__ __forceinline__ int tromp_taylor(BoardLds<NW>& L, const Geo<NW>& g, const uint32_t lab[]) {
+  constexpr int K = Geo<NW>::K;
   uint16_t* flag = reinterpret_cast<uint16_t*>(L.desc);  // padded image, LAB_N u16 <= TAB_N u32
-  for (int i = lane; i < LAB_N; i += 64) flag[i] = 0;
+  for (int i = g.tid; i < LAB_N; i += 64 * NW) flag[i] = 0;
+  board_any_init(L, g);
   WSYNC();
-  uint32_t f[KCH];
+  uint32_t f[K];
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
+  for (int k = 0; k < K; ++k) {
     f[k] = 0;
     if (g.p[k] < NPTS && lab[k] == 0) {
       uint32_t n[4];
@@ -446,61 +576,76 @@ __device__ __forceinline__ int tromp_taylor(WaveLds& L, const Geo& g, int lane, 
   for (int iter = 0; iter < 2 * NPTS; ++iter) {  // bounded: a fixed point is reached long before
     bool changed = false;
     GO_UNROLL
-    for (int k = 0; k < KCH; ++k) {
+    for (int k = 0; k < K; ++k) {
       if (g.p[k] < NPTS && lab[k] == 0) {
         const int c = g.c[k];
         const uint32_t nf = f[k] | flag[c - PW] | flag[c - 1] | flag[c + PW] | flag[c + 1];
         if (nf != f[k]) { f[k] = nf; flag[c] = (uint16_t)nf; changed = true; }
       }
-      WSYNC();
     }
-    if (!__any(changed)) break;
+    if (!board_any(L, g, changed, iter)) break;
   }
-  int black = 0, white = 0;
+  int diff = 0;
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
+  for (int k = 0; k < K; ++k) {
     const uint32_t col = col_of(lab[k]);
     const bool e = g.p[k] < NPTS && lab[k] == 0;
-    black += popc64(__ballot(col == 1 || (e && f[k] == 1)));
-    white += popc64(__ballot(col == 2 || (e && f[k] == 2)));
+    diff += popc64(__ballot(col == 1 || (e && f[k] == 1)));
+    diff -= popc64(__ballot(col == 2 || (e && f[k] == 2)));
   }
   WSYNC();
-  return black - white;
+  return board_sum(L, g, diff, 0);
 }
 
 // GetFastScore(board, RULE_CHINESE), go/board.cc:1560-1582: stones + true eyes per colour
 // (GetEyeColor tests white first, :1554-1558).
-__device__ __forceinline__ int fast_score_cn(const WaveLds& L, const Geo& g, const uint32_t lab[KCH],
+template <int NW>
+__device__ __forceinline__ int fast_score_cn(BoardLds<NW>& L, const Geo<NW>& g, const uint32_t lab[],
                                              const Scalars& s) {
-  Masks m;
-  unsigned long long eb[KCH], ew[KCH];
-  move_masks(L, g, lab, s, S_BLACK, m, eb);
-  move_masks(L, g, lab, s, S_WHITE, m, ew);
+  Own<NW> ob, ow;
+  move_masks(L, g, lab, s, S_BLACK, ob);
+  move_masks(L, g, lab, s, S_WHITE, ow);
   int sc = 0;
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
+  for (int k = 0; k < Geo<NW>::K; ++k) {
     const uint32_t col = col_of(lab[k]);
-    sc += popc64(__ballot(col == 1)) + popc64(eb[k] & ~ew[k]);
-    sc -= popc64(__ballot(col == 2)) + popc64(ew[k]);
+    sc += popc64(__ballot(col == 1)) + popc64(ob.eye[k] & ~ow.eye[k]);
+    sc -= popc64(__ballot(col == 2)) + popc64(ow.eye[k]);
   }
-  return sc;
+  return board_sum(L, g, sc, 1);
+}
+
+// Colour ballots of the whole board in every wave: wb/ww[0..5], [6] = 0.
+template <int NW>
+__device__ __forceinline__ void colour_words(BoardLds<NW>& L, const Geo<NW>& g, const uint32_t lab[],
+                                             unsigned long long wb[NWORDS + 1], unsigned long long ww[NWORDS + 1]) {
+  constexpr int K = Geo<NW>::K;
+  if (NW == 1) {
+    GO_UNROLL
+    for (int k = 0; k < K; ++k) {
+      wb[k] = __ballot(col_of(lab[k]) == 1);
+      ww[k] = __ballot(col_of(lab[k]) == 2);
+    }
+  } else {
+    GO_UNROLL
+    for (int k = 0; k < K; ++k) {
+      const unsigned long long b = __ballot(col_of(lab[k]) == 1), w = __ballot(col_of(lab[k]) == 2);
+      if (g.lane == 0) { L.xcol[NW * k + g.wave] = b; L.xcol[NWORDS + NW * k + g.wave] = w; }
+    }
+    WSYNC();
+    GO_UNROLL
+    for (int j = 0; j < NWORDS; ++j) { wb[j] = uni64(L.xcol[j]); ww[j] = uni64(L.xcol[NWORDS + j]); }
+  }
+  wb[NWORDS] = 0; ww[NWORDS] = 0;
 }
 
 // Exact L1 distance to the nearest black / white stone (GetDistanceMap + DistanceTransform,
-// go/board_feature.cc:17-38,148-160).  Pass 1 (along y) is a bit trick on the 19-bit column
-// occupancy, pass 2 (along x) the reference's forward/backward min-plus sweep, one lane per
-// (colour, y) line, fully unrolled in registers.  Returns has_black | has_white<<1.
-__device__ __forceinline__ int distance_maps(WaveLds& L, int lane, const uint32_t lab[KCH]) {
-  unsigned long long wb[KCH + 1], ww[KCH + 1];
-  GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
-    wb[k] = __ballot(col_of(lab[k]) == 1);
-    ww[k] = __ballot(col_of(lab[k]) == 2);
-  }
-  wb[KCH] = 0; ww[KCH] = 0;
-  int has = 0;
-  GO_UNROLL
-  for (int k = 0; k < KCH; ++k) { if (wb[k]) has |= 1; if (ww[k]) has |= 2; }
+// go/board_feature.cc:17-38,148-160) into L.dist, by ONE wave (lanes = (colour, y) lines).
+// Pass 1 (along y) is a bit trick on the 19-bit column occupancy, pass 2 (along x) the
+// reference's forward/backward min-plus sweep, fully unrolled in registers.
+template <int NW>
+__device__ __forceinline__ void distance_lines(BoardLds<NW>& L, int lane, const unsigned long long wb[NWORDS + 1],
+                                               const unsigned long long ww[NWORDS + 1]) {
   const bool white_lane = lane >= 32;
   const int y = lane & 31;
   int a[BS];
@@ -525,8 +670,6 @@ __device__ __forceinline__ int distance_maps(WaveLds& L, int lane, const uint32_
     GO_UNROLL
     for (int x = 0; x < BS; ++x) d[x * BS + y] = (uint8_t)a[x];
   }
-  WSYNC();
-  return has;
 }
 
 // BoardFeature::Transform (go/board_feature.h:38-48): output index of point p under a D4 code.
@@ -546,67 +689,116 @@ __device__ __forceinline__ int d4_dest(int code, int p) {
 // 16-B alignment is not available; gfx950 takes dwordx4 global stores at dword alignment at full
 // rate (tools/store_bench.hip).
 struct __attribute__((packed, aligned(4))) float4u { float x, y, z, w; };
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// One dwordx4 plane store.  WT = write-through (`sc1`): the bytes leave the XCD's L2 at once
+// instead of staying dirty there until the end-of-kernel write-back, so a launch that writes
+// tens of MB does not pay that write-back after its last wave has finished (the "publish-large"
+// row of MI355X_MICROARCH.md), and stores issued early really overlap the rules phase.
+template <bool WT>
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+  if (WT) {
+    const f32x4 v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v));
+  } else {
+    const float4u v = {a, b, c, d};
+    *reinterpret_cast<float4u*>(p) = v;
+  }
+}
+
+template <bool WT>
 __device__ __forceinline__ void zero_range(float* __restrict__ o, int count, int lane) {
-  const float4u z = {0.f, 0.f, 0.f, 0.f};
   const int body = count & ~3;
-  for (int i = 4 * lane; i < body; i += 256) *reinterpret_cast<float4u*>(o + i) = z;
+  for (int i = 4 * lane; i < body; i += 256) store4<WT>(o + i, 0.f, 0.f, 0.f, 0.f);
   if (lane < count - body) o[body + lane] = 0.f;
 }
 
-// BoardFeature::Extract (go/board_feature.cc:175-195): 25 planes x 361 floats.
+// The 11 planes that Extract never fills (12, 13: BORDER / POSITION_MARK; 16..24,
+// go/board_feature.h:13-28, board_feature.cc:178-179) are constant zeros.  They are 44 % of a
+// sample's bytes and depend on nothing, so a kernel issues them FIRST: the stores drain to HBM
+// while the workgroup is still in its latency-bound rules phase.
+template <int NW, bool WT>
+__device__ __forceinline__ void zero_planes(const Geo<NW>& g, float* __restrict__ out) {
+  constexpr int BIG = 9 * NPTS;                       // planes 16..24
+  constexpr int PART = ((BIG / NW) + 3) & ~3;         // per-wave slice, multiple of 4 floats
+  const int lo = g.wave * PART;
+  const int hi = (g.wave == NW - 1) ? BIG : lo + PART;
+  zero_range<WT>(out + 16 * NPTS + lo, hi - lo, g.lane);
+  if (g.wave == 0) zero_range<WT>(out + 12 * NPTS, 2 * NPTS, g.lane);
+}
+
+// BoardFeature::Extract (go/board_feature.cc:175-195): the 14 planes that carry data and, when
+// ZEROS, the 11 constant ones too (otherwise the caller has issued zero_planes for them).
 // Store shape: plane-major, each plane as two dwordx4 wave-stores (lane l: q = 4l..4l+3, then
 // q = 256+4l..; lane 26 covers 357..360, re-writing 3 floats with the same values), so a board's
-// 36,100 B leave the wave as ascending contiguous runs -- 45 store instructions instead of 150
-// dword stores, and 1.6x the HBM rate of point-major dword stores at 65,536 boards.
+// 36,100 B leave as ascending contiguous runs -- 45 store instructions instead of 150 dword
+// stores, and 1.6x the HBM rate of point-major dword stores at 65,536 boards.
+// Work split when NW > 1: wave 0 runs the distance transform while the other waves already
+// stream out the 12 planes that do not depend on it; planes 14/15 follow.
 // `lut` = host-built (float)exp(-d/10.0) table (board_feature.cc:141).
-__device__ __forceinline__ void write_features(WaveLds& L, const Geo& g, int lane, const uint32_t lab[KCH],
-                                               const uint32_t lastp[KCH], const Scalars& s, int aug,
-                                               const float* __restrict__ lut, float* __restrict__ out) {
-  // history values first: their global-load latency hides under the distance transform
-  float hv[KCH];
+// History values are table loads; they are issued right after the record load (history_preload),
+// for the ply the position will have when the planes are written, so that they neither wait
+// behind the kernel's own stores nor sit on the critical path.  `pre_ply` = that assumed ply;
+// if the position ended up elsewhere (restart, rejected move) the values are loaded again.
+// A stone of age 1 is the one just placed (its preload used a stale last_placed): lut1 = lut[1].
+template <int NW>
+__device__ __forceinline__ void history_preload(const Geo<NW>& g, const uint32_t lastp[], int pre_ply,
+                                                const float* __restrict__ lut, float hv_pre[]) {
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
+  for (int k = 0; k < Geo<NW>::K; ++k) {
+    int age = pre_ply - (int)lastp[k];
+    age = age < 0 ? 0 : (age > HIST_LUT_N - 1 ? HIST_LUT_N - 1 : age);
+    hv_pre[k] = (g.p[k] < NPTS) ? lut[age] : 0.f;
+  }
+}
+
+template <int NW, bool ZEROS, bool WT>
+__device__ __forceinline__ void write_features(BoardLds<NW>& L, const Geo<NW>& g, const uint32_t lab[],
+                                               const uint32_t lastp[], const Scalars& s, int aug,
+                                               const float* __restrict__ lut, float* __restrict__ out,
+                                               const float hv_pre[], int pre_ply, float lut1) {
+  constexpr int K = Geo<NW>::K;
+  const int lane = g.lane;
+  float hv[K];
+  GO_UNROLL
+  for (int k = 0; k < K; ++k) {
     hv[k] = 0.f;
     if (g.p[k] < NPTS && lab[k]) {
       int age = s.ply - (int)lastp[k];
       age = age < 0 ? 0 : (age > HIST_LUT_N - 1 ? HIST_LUT_N - 1 : age);
-      hv[k] = lut[age];
+      if (s.ply == pre_ply) hv[k] = age == 1 ? lut1 : hv_pre[k];
+      else hv[k] = lut[age];
     }
   }
-  const int has = distance_maps(L, lane, lab);
+  unsigned long long wb[NWORDS + 1], ww[NWORDS + 1];
+  colour_words(L, g, lab, wb, ww);
+  int has = 0;
+  GO_UNROLL
+  for (int j = 0; j < NWORDS; ++j) { if (wb[j]) has |= 1; if (ww[j]) has |= 2; }
   const int ko_p = (s.koage == 0 && s.ko >= 0) ? s.ko : -1;  // GetSimpleKoLocation, board.cc:337-344
   // per-point descriptor, scattered to its OUTPUT index (D4 applied here):
-  //   colour(2) | cls(2) | ko(1) | d_black(7) | d_white(7);  history value in a parallel table
-  float* hist = reinterpret_cast<float*>(L.lib);  // the liberty table is dead from here on
+  //   colour(2) | cls(2) | ko(1);  history value in a parallel table (the liberty table is dead)
+  float* hist = reinterpret_cast<float*>(L.lib);
+  int q[K];
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k) {
+  for (int k = 0; k < K; ++k) {
+    q[k] = 0;
     if (g.p[k] < NPTS) {
       uint32_t d = typ_of(lab[k]);  // cls 1,2,3 <-> GetLibertyMap3binary :83-99
       if (g.p[k] == ko_p) d |= 16u;
-      d |= (uint32_t)L.dist[0][g.p[k]] << 5;
-      d |= (uint32_t)L.dist[1][g.p[k]] << 12;
-      const int q = aug ? d4_dest(aug, g.p[k]) : g.p[k];
-      L.desc[q] = d;
-      hist[q] = hv[k];
+      q[k] = aug ? d4_dest(aug, g.p[k]) : g.p[k];
+      L.desc[q[k]] = d;
+      hist[q[k]] = hv[k];
     }
   }
   WSYNC();
   const uint32_t our = (uint32_t)s.next, opp = 3u - our;
   const bool has_our = (has >> (our - 1)) & 1, has_opp = (has >> (opp - 1)) & 1;
-  const int sh_our = our == 1 ? 5 : 12, sh_opp = our == 1 ? 12 : 5;
   const int qa = 4 * lane;
   const int qb = lane < 26 ? 256 + 4 * lane : NPTS - 4;
+  const bool act_b = lane <= 26;
   uint32_t d[8];
   float h[8];
-  GO_UNROLL
-  for (int i = 0; i < 4; ++i) {
-    d[i] = L.desc[qa + i];
-    h[i] = hist[qa + i];
-    d[4 + i] = L.desc[qb + i];
-    h[4 + i] = hist[qb + i];
-  }
-  const bool act_b = lane <= 26;
 
 #define GO_PLANE(pl, EXPR)                                                          \
   do {                                                                              \
@@ -620,35 +812,70 @@ __device__ __forceinline__ void write_features(WaveLds& L, const Geo& g, int lan
       (void)cls; (void)mine; (void)theirs; (void)hh;                                \
       v_[i] = (EXPR);                                                               \
     }                                                                               \
-    const float4u a_ = {v_[0], v_[1], v_[2], v_[3]};                                \
-    const float4u b_ = {v_[4], v_[5], v_[6], v_[7]};                                \
-    *reinterpret_cast<float4u*>(out + (pl) * NPTS + qa) = a_;                       \
-    if (act_b) *reinterpret_cast<float4u*>(out + (pl) * NPTS + qb) = b_;            \
+    store4<WT>(out + (pl) * NPTS + qa, v_[0], v_[1], v_[2], v_[3]);                 \
+    if (act_b) store4<WT>(out + (pl) * NPTS + qb, v_[4], v_[5], v_[6], v_[7]);      \
   } while (0)
 
-  GO_PLANE(0, (mine && cls == 1) ? 1.f : 0.f);
-  GO_PLANE(1, (mine && cls == 2) ? 1.f : 0.f);
-  GO_PLANE(2, (mine && cls != 1 && cls != 2) ? 1.f : 0.f);  // literally "else", board_feature.cc:93
-  GO_PLANE(3, (theirs && cls == 1) ? 1.f : 0.f);
-  GO_PLANE(4, (theirs && cls == 2) ? 1.f : 0.f);
-  GO_PLANE(5, (theirs && cls != 1 && cls != 2) ? 1.f : 0.f);
-  GO_PLANE(6, (dd & 16u) ? 1.f : 0.f);
-  GO_PLANE(7, mine ? 1.f : 0.f);
-  GO_PLANE(8, theirs ? 1.f : 0.f);
-  GO_PLANE(9, col == 0 ? 1.f : 0.f);
-  GO_PLANE(10, mine ? hh : 0.f);
-  GO_PLANE(11, theirs ? hh : 0.f);
-  zero_range(out + 12 * NPTS, 2 * NPTS, lane);               // BORDER, POSITION_MARK: never filled
-  GO_PLANE(14, has_our ? (float)((dd >> sh_our) & 127u) : 10000.f);
-  GO_PLANE(15, has_opp ? (float)((dd >> sh_opp) & 127u) : 10000.f);
-  zero_range(out + 16 * NPTS, 9 * NPTS, lane);               // planes 16..24: never filled
+  // the 12 planes that need no distance, as 4 store groups dealt round-robin to the storing
+  // waves (all waves but wave 0 when NW > 1)
+  constexpr int NS = NW > 1 ? NW - 1 : 1;                 // storing waves in this phase
+  const int sw = NW > 1 ? g.wave - 1 : 0;                 // this wave's index among them (-1: wave 0)
+  if (NW == 1 || g.wave > 0) {
+    GO_UNROLL
+    for (int i = 0; i < 4; ++i) {
+      d[i] = L.desc[qa + i];
+      h[i] = hist[qa + i];
+      d[4 + i] = L.desc[qb + i];
+      h[4 + i] = hist[qb + i];
+    }
+    if (0 % NS == sw) {
+      GO_PLANE(0, (mine && cls == 1) ? 1.f : 0.f);
+      GO_PLANE(1, (mine && cls == 2) ? 1.f : 0.f);
+      GO_PLANE(2, (mine && cls != 1 && cls != 2) ? 1.f : 0.f);  // literally "else", board_feature.cc:93
+    }
+    if (1 % NS == sw) {
+      GO_PLANE(3, (theirs && cls == 1) ? 1.f : 0.f);
+      GO_PLANE(4, (theirs && cls == 2) ? 1.f : 0.f);
+      GO_PLANE(5, (theirs && cls != 1 && cls != 2) ? 1.f : 0.f);
+    }
+    if (2 % NS == sw) {
+      GO_PLANE(6, (dd & 16u) ? 1.f : 0.f);
+      GO_PLANE(7, mine ? 1.f : 0.f);
+      GO_PLANE(8, theirs ? 1.f : 0.f);
+    }
+    if (3 % NS == sw) {
+      GO_PLANE(9, col == 0 ? 1.f : 0.f);
+      GO_PLANE(10, mine ? hh : 0.f);
+      GO_PLANE(11, theirs ? hh : 0.f);
+      if (ZEROS) zero_range<WT>(out + 12 * NPTS, 2 * NPTS, lane);   // BORDER, POSITION_MARK: never filled
+    }
+    if (ZEROS) {                                                // planes 16..24: never filled
+      if (4 % NS == sw) zero_range<WT>(out + 16 * NPTS, 4 * NPTS, lane);
+      if (5 % NS == sw) zero_range<WT>(out + 20 * NPTS, 5 * NPTS, lane);
+    }
+  }
+  if (g.wave == 0) distance_lines(L, lane, wb, ww);
+  WSYNC();
+  // distances to the output index, packed into the (now free) descriptor table
+  GO_UNROLL
+  for (int k = 0; k < K; ++k)
+    if (g.p[k] < NPTS) L.desc[q[k]] = (uint32_t)L.dist[0][g.p[k]] | ((uint32_t)L.dist[1][g.p[k]] << 8);
+  WSYNC();
+  const int sh_our = our == 1 ? 0 : 8, sh_opp = our == 1 ? 8 : 0;
+  if (g.wave == 0 || (NW > 1 && g.wave == 1)) {
+    GO_UNROLL
+    for (int i = 0; i < 4; ++i) { d[i] = L.desc[qa + i]; d[4 + i] = L.desc[qb + i]; h[i] = 0.f; h[4 + i] = 0.f; }
+    if (g.wave == 0) GO_PLANE(14, has_our ? (float)((dd >> sh_our) & 255u) : 10000.f);
+    if (NW == 1 || g.wave == 1) GO_PLANE(15, has_opp ? (float)((dd >> sh_opp) & 255u) : 10000.f);
+  }
 #undef GO_PLANE
 }
 
-__device__ __forceinline__ void write_legal(const Geo& g, int lane, const Masks& m, uint8_t* __restrict__ out) {
+template <int NW>
+__device__ __forceinline__ void write_legal(const Geo<NW>& g, const Own<NW>& o, uint8_t* __restrict__ out) {
   GO_UNROLL
-  for (int k = 0; k < KCH; ++k)
-    if (g.p[k] < NPTS) out[g.p[k]] = (uint8_t)((m.legal[k] >> lane) & 1ull);
+  for (int k = 0; k < Geo<NW>::K; ++k)
+    if (g.p[k] < NPTS) out[g.p[k]] = (uint8_t)((o.legal[k] >> g.lane) & 1ull);
 }
 
 }  // namespace goenv

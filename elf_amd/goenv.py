@@ -42,6 +42,7 @@ _SIGS = {
     "goenv_create": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_float, C.c_int, C.POINTER(C.c_void_p)]),
     "goenv_destroy": (C.c_int, [C.c_void_p]),
     "goenv_num_boards": (C.c_int, [C.c_void_p]),
+    "goenv_set_waves_per_board": (C.c_int, [C.c_void_p, C.c_int]),
     "goenv_state_ptr": (C.c_void_p, [C.c_void_p]),
     "goenv_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "goenv_get_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_void_p]),
@@ -166,6 +167,9 @@ class GoEnv:
             self.close()
         except Exception:
             pass
+
+    def set_waves_per_board(self, nw):
+        self._chk(self.lib.goenv_set_waves_per_board(self._h, int(nw)))
 
     def new(self, dtype, *shape):
         return torch.zeros((self.n,) + tuple(shape), dtype=dtype, device=self.device)

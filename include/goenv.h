@@ -152,6 +152,9 @@ int goenv_create(int device, int n_boards, uint64_t seed, int64_t board_id_base,
                  float komi, int max_ply, goenv_ctx** out);
 int goenv_destroy(goenv_ctx* ctx);
 int goenv_num_boards(const goenv_ctx* ctx);
+/* Launch shape: wavefronts that share one board (1, 2, 3 or 6; 0 = chosen per launch from the
+ * batch size, the default).  Results do not depend on it.  No counterpart in the reference. */
+int goenv_set_waves_per_board(goenv_ctx* ctx, int nw);
 /* device pointer to the packed records [n_boards][GOENV_REC_BYTES] */
 void* goenv_state_ptr(goenv_ctx* ctx);
 

@@ -15,3 +15,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(params=[0, 1, 2, 3, 6], ids=lambda v: "waves%d" % v)
+def waves_per_board(request):
+    """Runs a GPU test once per launch shape of the kernels (wavefronts that share one board;
+    0 = chosen per launch from the batch size).  Results must not depend on it."""
+    if request.param:
+        os.environ["GOENV_WAVES_PER_BOARD"] = str(request.param)
+    else:
+        os.environ.pop("GOENV_WAVES_PER_BOARD", None)
+    yield request.param
+    os.environ.pop("GOENV_WAVES_PER_BOARD", None)

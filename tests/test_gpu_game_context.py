@@ -15,7 +15,7 @@ import pytest
 from common import GOLDEN, assert_planes_equal, load_golden
 from oracle.pyoracle import FNV_SEED, OracleBoard, fnv_planes
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("waves_per_board")]
 torch = pytest.importorskip("torch")
 
 NP_TYPES = {"int32_t": "i4", "int64_t": "i8", "float": "f4", "unsigned char": "u1", "char": "i1"}

@@ -9,7 +9,7 @@ import pytest
 from common import (EDGE_CASES, GOLDEN, assert_canon_equal, assert_planes_equal, load_golden, position_digest)
 from oracle.pyoracle import OracleBoard
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("waves_per_board")]
 
 torch = pytest.importorskip("torch")
 

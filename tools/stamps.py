@@ -33,7 +33,7 @@ for rep in range(20):
 acc /= 20
 med = acc.median(0).values
 tot = (s[:, 7] - s[:, 0]).double()
-print("boards", B, "median wave cycles (s_memtime ticks @100MHz? see guide) per phase:")
+print("boards", B, "waves/board", os.environ.get("GOENV_WAVES_PER_BOARD", "auto"), "median cycles of wave 0 per phase:")
 for i, k in enumerate([1, 2, 3, 4, 5, 6, 7]):
     print("  %-14s %9.0f  (%.1f%%)" % (names[k], med[i].item(), 100 * med[i].item() / med.sum().item()))
 print("  total median %.0f  max %.0f" % (tot.median().item(), tot.max().item()))
