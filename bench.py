@@ -51,6 +51,18 @@ def cpu_baseline(budget_sec=12.0):
     }
 
 
+def measured_traffic(boards):
+    """HBM bytes per launch from the PMC passes of this round (FETCH_SIZE x2 + WRITE_SIZE, corrected
+    as MI355X_MICROARCH.md prescribes; collected by tools/profile_round.sh on the same command and
+    committed as profiles/r01_pmc.json).  None when no pass exists for this batch size."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
+            d = json.load(f)
+        return float(d["traffic_bytes"]) if int(d["boards"]) == boards else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,13 +134,15 @@ def main():
         "metric": "19x19 Go moves/sec (node, 1/2/4/8 GPU) + feature-extract HBM GB/s",
         "value": value, "unit": "moves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "i32 rules + f32 planes", "data": "synthetic",
+        "vs_baseline": None, "dtype": "i32", "data": "synthetic",
         "config": {"workload": "cfg2: %d concurrent 19x19 games per GPU, on-device uniform-random legal-move "
                                "playouts to the end (restart in place), fused step + legal mask + 25 planes "
                                "per ply" % B,
                    "boards_per_gpu": B, "global_boards": world * B, "ply_cap": 722, "parallelism": "shard%d" % world},
         "roofline": {"bound": "hbm", "kernel": "k_ply<random>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B),
+                     "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc.md)",
+                     "algorithmic_bytes_per_launch": B * ALG_BYTES_PER_BOARD,
                      "bytes_per_board": ALG_BYTES_PER_BOARD, "kernel_ms": kernel_ms},
         "feature_extract_GBps": achieved,
         "stats": {"games": stats[0], "black_wins": stats[1], "white_wins": stats[2], "plies": stats[4],
