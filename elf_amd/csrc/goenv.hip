@@ -169,13 +169,11 @@ __global__ __launch_bounds__(64 * NW) void k_ply(PlyParams P) {
   STAMP(0);
   BoardRec* rec = P.state + board;
   Scalars s;
-  load_scalars(rec, s);
   uint32_t lab[K], lastp[K];
   Masks m;
   Own<NW> o;
-  load_masks(rec, m);
+  load_record(rec, L, g, lab, lastp, s, m);
   own_from_masks(g, m, o);
-  load_board(rec, L, g, lab, lastp);
   float hv_pre[K];
   const int pre_ply = s.ply + 1;  // every accepted move, pass included, advances the ply by one
   if (P.feat) {
@@ -251,9 +249,9 @@ __global__ __launch_bounds__(64 * NW) void k_features(BoardRec* state, int n_tot
   constexpr int K = Geo<NW>::K;
   BoardRec* rec = state + board;
   Scalars s;
-  load_scalars(rec, s);
   uint32_t lab[K], lastp[K];
-  load_board(rec, L, g, lab, lastp);
+  Masks m;
+  load_record(rec, L, g, lab, lastp, s, m);
   float hv_pre[K];
   if (feat) {
     history_preload(g, lastp, s.ply, lut, hv_pre);
@@ -268,9 +266,7 @@ __global__ __launch_bounds__(64 * NW) void k_features(BoardRec* state, int n_tot
     if (g.tid == 0) { rec->sc[SC_SEQ] = s.seq; rec->sc[SC_SEQTOT] = s.seqtot; }
   }
   if (legal) {
-    Masks m;
     Own<NW> o;
-    load_masks(rec, m);
     own_from_masks(g, m, o);
     write_legal(g, o, legal + (size_t)b * NPTS);
   }
@@ -555,13 +551,11 @@ __global__ __launch_bounds__(64 * NW) void k_playout(PlyParams P, int16_t* moves
   constexpr int K = Geo<NW>::K;
   BoardRec* rec = P.state + b;
   Scalars s;
-  load_scalars(rec, s);
   uint32_t lab[K], lastp[K];
   Masks m;
   Own<NW> o;
-  load_masks(rec, m);
+  load_record(rec, L, g, lab, lastp, s, m);
   own_from_masks(g, m, o);
-  load_board(rec, L, g, lab, lastp);
   int cnt = 0;
   // exit condition every wave reaches: done flag (uniform), or the hard bound on iterations
   for (int it = 0; it < 4096 && !s.done; ++it) {
@@ -594,13 +588,11 @@ __global__ __launch_bounds__(64 * NW) void k_replay(PlyParams P, const int16_t* 
   }
   BoardRec* rec = P.state + board;
   Scalars s;
-  load_scalars(rec, s);
   uint32_t lab[K], lastp[K];
   Masks m;
   Own<NW> o;
-  load_masks(rec, m);
+  load_record(rec, L, g, lab, lastp, s, m);
   own_from_masks(g, m, o);
-  load_board(rec, L, g, lab, lastp);
   int n = nmoves[b];
   n = __builtin_amdgcn_readfirstlane(n < 0 ? 0 : (n > stride ? stride : n));
   int cnt = 0;

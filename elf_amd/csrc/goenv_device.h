@@ -66,8 +66,11 @@ static_assert(sizeof(BoardRec) == 1632, "record layout");
 
 // Per-board LDS working set (~5 KB -> 32 single-wave boards per CU fit in 160 KB).
 template <int NW>
-struct BoardLds {
-  uint32_t lib[TAB_N + 64 * NW];  // liberties by root (+ one sink slot per thread for masked atomics)
+struct __attribute__((aligned(16))) BoardLds {
+  // liberties by root (+ one sink slot per thread for masked atomics); while no liberty count is
+  // live it doubles as the staging image of the record's per-point tables (load_record) and as
+  // the history-value table of write_features
+  uint32_t lib[TAB_N + 64 * NW];
   uint32_t desc[TAB_N];           // per-point feature descriptor; also flood-fill scratch
   uint16_t lab[LAB_N];            // padded label image
   uint8_t dist[2][TAB_N];         // L1 distance to nearest black / white stone
@@ -198,6 +201,31 @@ __device__ __forceinline__ void load_masks(const BoardRec* rec, Masks& m) {
   for (int j = 0; j < NWORDS; ++j) { m.legal[j] = rec->legal[j]; m.cand[j] = rec->cand[j]; }
 }
 
+// HBM record -> LDS -> registers: the two per-point tables with ONE 16-B load per thread (92 of
+// them) instead of 2-byte loads per point: the vector-memory pipe takes as long for a
+// 128-B wave-instruction as for a 1-KB one, and a record arrives in a single round trip.
+constexpr int LABS_VEC = (2 * TAB_N * 2) / 16;         // 92: the two per-point tables
+template <int NW>
+__device__ __forceinline__ void load_record(const BoardRec* rec, BoardLds<NW>& L, const Geo<NW>& g,
+                                            uint32_t lab[], uint32_t lastp[], Scalars& s, Masks& m) {
+  load_scalars(rec, s);   // scalar loads: back early, the move choice starts from them
+  load_masks(rec, m);
+  uint4* stage = reinterpret_cast<uint4*>(L.lib);
+  const uint4* src = reinterpret_cast<const uint4*>(rec);
+  for (int i = g.tid; i < LABS_VEC; i += 64 * NW) stage[i] = src[i];
+  fill_rim(L, g.tid);
+  WSYNC();
+  const uint16_t* raw = reinterpret_cast<const uint16_t*>(L.lib);
+  GO_UNROLL
+  for (int k = 0; k < Geo<NW>::K; ++k) {
+    const bool v = g.p[k] < NPTS;
+    lab[k] = v ? raw[g.p[k]] : 0u;
+    lastp[k] = v ? raw[TAB_N + g.p[k]] : 0u;
+    if (v) L.lab[g.c[k]] = (uint16_t)lab[k];
+  }
+  WSYNC();  // image complete; the staging area (the liberty table) may be rewritten from here on
+}
+
 // this wave's words of the uniform six-word masks
 template <int NW>
 __device__ __forceinline__ void own_from_masks(const Geo<NW>& g, const Masks& m, Own<NW>& o) {
@@ -293,6 +321,9 @@ __device__ __forceinline__ void board_any_init(BoardLds<NW>& L, const Geo<NW>& g
   }
 }
 
+// registers -> HBM record.  (Staging the record through LDS for 16-B stores, as load_record does for
+// the load, was measured slower in the fused ply: its three extra barriers cost more than the
+// narrow stores, which are fire-and-forget.)
 template <int NW>
 __device__ __forceinline__ void store_board(BoardRec* rec, const Geo<NW>& g, const uint32_t lab[],
                                             const uint32_t lastp[], const Own<NW>& o, const Scalars& s) {
