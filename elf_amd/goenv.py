@@ -228,6 +228,19 @@ class GoEnv:
             return _ptr(idx), 0, idx.numel()
         return None, int(first), int(self.n - first if count is None else count)
 
+    def get_state_sel(self, idx=None, first=0, count=None):
+        ip, first, count = self._sel(idx, first, count)
+        dev = self.device
+        out = dict(color=torch.zeros((count, NUM_POINTS), dtype=torch.uint8, device=dev),
+                   liberties=torch.zeros((count, NUM_POINTS), dtype=torch.int16, device=dev),
+                   stones=torch.zeros((count, NUM_POINTS), dtype=torch.int16, device=dev),
+                   last_placed=torch.zeros((count, NUM_POINTS), dtype=torch.uint16, device=dev),
+                   scalars=torch.zeros((count, 16), dtype=torch.int32, device=dev))
+        self._chk(self.lib.goenv_get_state_sel(self._h, ip, first, count, _ptr(out["color"]), _ptr(out["liberties"]),
+                                               _ptr(out["stones"]), _ptr(out["last_placed"]), _ptr(out["scalars"]),
+                                               self._stream()))
+        return out
+
     def ply_sel(self, idx=None, first=0, count=None, flags=0, actions=None, aug_codes=None, feat_out=None,
                 legal_out=None, meta=None, actions_out=None, status_out=None):
         """goenv_ply_sel: batch arrays are indexed by the selection row."""

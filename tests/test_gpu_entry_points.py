@@ -1,0 +1,167 @@
+"""GPU parity tests of the remaining C-ABI entry points (through elf_amd/goenv.py): policy
+sampling, move-list replay, selections, sequencing records.  Bit-exact against the CPU oracle."""
+import numpy as np
+import pytest
+
+from common import assert_canon_equal, assert_planes_equal, load_golden
+from oracle.pyoracle import OracleBoard
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("waves_per_board")]
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def goenv():
+    from elf_amd import goenv as m
+    m.load_library()
+    assert torch.cuda.is_available()
+    return m
+
+
+def midgame(goenv, B, seed, plies):
+    """B boards advanced by the on-device policy, with their oracle twins."""
+    env = goenv.GoEnv(B, seed=seed, max_ply=722)
+    acts = env.new(torch.int32)
+    oracles = [OracleBoard() for _ in range(B)]
+    for _ in range(plies):
+        env.ply(goenv.F_RANDOM_POLICY, actions_out=acts)
+        for b, a in enumerate(acts.cpu().tolist()):
+            assert oracles[b].forward(a)[0]
+    return env, oracles
+
+
+def test_sample_policy_matches_oracle(goenv):
+    B, seed = 40, 77
+    env, oracles = midgame(goenv, B, seed, 90)
+    rng = np.random.RandomState(3)
+    pi = rng.rand(B, 361).astype(np.float32)
+    pi[1] = 0.0                                  # all-zero row: falls back to the cfg-2 policy
+    pi[2] = -1.0                                 # nothing positive: same
+    pi[3] *= 5.0                                 # weights above 1 saturate at 2^24
+    pi[4, :] = 0.0
+    pi[4, np.flatnonzero(oracles[4].legal())[:3]] = [1e-9, 0.5, 2e-8]   # tiny weights floor to 0
+    pi[5] = np.where(oracles[5].legal() > 0, 0.0, 1.0)                  # all mass on illegal points
+    augs = (np.arange(B) % 8).astype(np.int32)
+    out = torch.zeros(B, dtype=torch.int64, device=env.device)
+    env.sample_policy(torch.from_numpy(pi).to(env.device), out, aug_codes=torch.from_numpy(augs).to(env.device))
+    got = out.cpu().tolist()
+    for b, o in enumerate(oracles):
+        want = o.sample_policy(seed, b, 0, pi[b], int(augs[b]))
+        assert got[b] == want, "board %d: GPU %d, oracle %d" % (b, got[b], want)
+        assert got[b] == -1 or o.legal()[got[b]] == 1
+    # a selection: rows follow idx
+    idx = torch.tensor([7, 3, 30], dtype=torch.int32, device=env.device)
+    out3 = torch.zeros(3, dtype=torch.int64, device=env.device)
+    env.sample_policy(torch.from_numpy(pi[[7, 3, 30]]).to(env.device), out3, idx=idx,
+                      aug_codes=torch.from_numpy(augs[[7, 3, 30]]).to(env.device))
+    assert out3.cpu().tolist() == [got[7], got[3], got[30]]
+    env.close()
+
+
+def test_replay_move_lists_and_stop_at_illegal(goenv):
+    g = load_golden("playouts.json")
+    games = g["games"][:6]
+    B = len(games) + 2
+    env = goenv.GoEnv(B, seed=1)
+    stride = 700
+    moves = np.full((B, stride), -1, np.int16)
+    nm = np.zeros(B, np.int32)
+    want_applied = []
+    oracles = [OracleBoard() for _ in range(B)]
+    for b, game in enumerate(games):
+        mv = list(game["moves"])
+        if b % 2 == 1:                            # corrupt: repeat an earlier (occupied) point
+            cut = 40 + 10 * b
+            mv = mv[:cut] + [mv[5]] + mv[cut:]
+        mv = mv[:stride]
+        moves[b, :len(mv)] = mv
+        nm[b] = len(mv)
+        n = 0
+        for a in mv:
+            if not oracles[b].forward(a)[0]:
+                break
+            n += 1
+        want_applied.append(n)
+    nm[B - 2] = 0                                 # empty list: board untouched
+    want_applied.append(0)
+    moves[B - 1, :3] = [-1, 60, -1]               # passes are moves too
+    nm[B - 1] = 3
+    for a in (-1, 60, -1):
+        oracles[B - 1].forward(a)
+    want_applied.append(3)
+    napplied = env.new(torch.int32)
+    env.replay(torch.from_numpy(moves).to(env.device), torch.from_numpy(nm).to(env.device), napplied)
+    assert napplied.cpu().tolist() == want_applied
+    assert any(w < n for w, n in zip(want_applied, nm.tolist()))
+    feat, legal = env.new(torch.float32, 25, 19, 19), env.new(torch.uint8, 361)
+    env.features(feat, None, legal)
+    st = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+    for b, o in enumerate(oracles):
+        assert_canon_equal({k: v[b] for k, v in st.items()}, o.canonical(), "board %d" % b)
+        assert np.array_equal(legal[b].cpu().numpy(), o.legal())
+        assert_planes_equal(feat[b].cpu().numpy(), o.extract(0), "board %d" % b)
+    env.close()
+
+
+def test_selections_and_sequencing_records(goenv):
+    """ply_sel / collect_sel on an index list: rows follow the list, untouched boards stay
+    untouched; sequencing record in both modes (episodes / the reference's run-on selfplay)."""
+    B, seed = 16, 5
+    env, oracles = midgame(goenv, B, seed, 30)
+    dev = env.device
+    sel = [11, 2, 7, 13]
+    idx = torch.tensor(sel, dtype=torch.int32, device=dev)
+    n = len(sel)
+    meta = dict(id=torch.zeros(n, dtype=torch.int32, device=dev), seq=torch.zeros(n, dtype=torch.int32, device=dev),
+                game_counter=torch.zeros(n, dtype=torch.int32, device=dev),
+                last_terminal=torch.zeros(n, dtype=torch.int8, device=dev),
+                move_idx=torch.zeros(n, dtype=torch.int32, device=dev),
+                winner=torch.ones(n, dtype=torch.int32, device=dev),
+                aug_code=torch.zeros(n, dtype=torch.int32, device=dev),
+                game_record_idx=torch.zeros(n, dtype=torch.int32, device=dev))
+    feat = torch.zeros(n, 25, 19, 19, device=dev)
+    legal = torch.zeros(n, 361, dtype=torch.uint8, device=dev)
+    augs = torch.tensor([0, 5, 2, 7], dtype=torch.int32, device=dev)
+    for rep in range(3):
+        env.collect_sel(idx=idx, aug_codes=augs, feat_out=feat, legal_out=legal, meta=meta)
+        assert meta["id"].cpu().tolist() == sel and meta["seq"].cpu().tolist() == [rep] * n
+        assert meta["game_counter"].cpu().tolist() == [0] * n and meta["last_terminal"].cpu().tolist() == [0] * n
+        assert meta["move_idx"].cpu().tolist() == [31] * n and meta["winner"].cpu().tolist() == [0] * n
+        assert meta["aug_code"].cpu().tolist() == [0, 5, 2, 7] and meta["game_record_idx"].cpu().tolist() == [-1] * n
+    for r, b in enumerate(sel):
+        assert_planes_equal(feat[r].cpu().numpy(), oracles[b].extract(int(augs[r])), "row %d" % r)
+        assert np.array_equal(legal[r].cpu().numpy(), oracles[b].legal())
+    # an illegal action with RESET_ILLEGAL restarts that game only; the others play on
+    acts = []
+    for r, b in enumerate(sel):
+        lg = np.flatnonzero(oracles[b].legal())
+        acts.append(int(np.flatnonzero(oracles[b].canonical()["color"])[0]) if r == 1 else int(lg[0]))
+    status = torch.zeros(n, dtype=torch.int32, device=dev)
+    env.ply_sel(idx=idx, flags=goenv.F_RESET_ILLEGAL, actions=torch.tensor(acts, dtype=torch.int64, device=dev),
+                status_out=status)
+    assert status.cpu().tolist() == [1, 0, 1, 1]
+    for r, b in enumerate(sel):
+        if r == 1:
+            oracles[b] = OracleBoard()
+        else:
+            assert oracles[b].forward(acts[r])[0]
+    st = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+    for b, o in enumerate(oracles):
+        assert_canon_equal({k: v[b] for k, v in st.items()}, o.canonical(), "board %d" % b)
+    # episodes mode: the restarted game reports a new episode; run-on mode keeps counting
+    env.collect_sel(idx=idx, meta=meta)
+    assert meta["seq"].cpu().tolist() == [3, 0, 3, 3] and meta["game_counter"].cpu().tolist() == [0, 1, 0, 0]
+    assert meta["last_terminal"].cpu().tolist() == [0, 1, 0, 0] and meta["move_idx"].cpu().tolist() == [32, 1, 32, 32]
+    so = goenv.SampleOut.from_tensors(meta, mode=1)
+    import ctypes as C
+    env._chk(env.lib.goenv_collect_sel(env._h, C.c_void_p(idx.data_ptr()), 0, n, None, None, None, C.byref(so),
+                                       env._stream()))
+    assert meta["seq"].cpu().tolist() == [4, 4, 4, 4] and meta["game_counter"].cpu().tolist() == [0] * n
+    assert meta["last_terminal"].cpu().tolist() == [0] * n
+    sub = {k: v.cpu().numpy() for k, v in env.get_state_sel(idx=idx).items()}
+    for r, b in enumerate(sel):
+        assert_canon_equal({k: v[r] for k, v in sub.items()}, oracles[b].canonical(), "sel row %d" % r)
+    # errors: out-of-range selection is reported, not fatal
+    with pytest.raises(goenv.GoEnvError):
+        env.collect_sel(first=10, count=10, feat_out=feat)
+    env.close()
