@@ -191,6 +191,23 @@ def extra_measurements(goenv, seed):
         res["boards_%d" % B] = r
         env.close()
         del feat, legal
+    # persistent generator: 64 plies per launch into ring buffers (2.4 GB of planes: a true HBM stream)
+    env = goenv.GoEnv(1024, seed=seed, max_ply=722)
+    T = 64
+    fr = torch.zeros(T, 1024, 25, 19, 19, device=env.device)
+    lr = torch.zeros(T, 1024, 361, dtype=torch.uint8, device=env.device)
+    for _ in range(3):
+        env.generate(T, fr, lr)
+    torch.cuda.synchronize()
+    env.timer_begin()
+    for _ in range(6):
+        env.generate(T, fr, lr)
+    env.timer_end()
+    ms = env.timer_ms() / (6 * T)
+    res["persistent_generate_1024"] = {"ply_ms": ms, "moves_per_s": 1024 / (ms * 1e-3), "plies_per_launch": T,
+                                       "GBps": 1024 * (ALG_BYTES_PLANES + ALG_BYTES_LEGAL) / (ms * 1e-3) / 1e9}
+    env.close()
+    del fr, lr
     env = goenv.GoEnv(1024, seed=seed, max_ply=722)
     nm = env.new(torch.int32)
     env.playout(None, nm)

@@ -568,6 +568,48 @@ __global__ __launch_bounds__(64 * NW) void k_playout(PlyParams P, int16_t* moves
   if (nmoves && g.tid == 0) nmoves[b] = cnt;
 }
 
+// Persistent generator: `n_plies` plies of the on-device policy per board inside one launch, ply
+// t's mask / planes / move written to slot t of the caller's ring buffers.  The board stays in
+// LDS/registers; boards drift apart in time, so the rules phase of one overlaps the plane stores
+// of another (what a launch per ply cannot do at small batch sizes).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_generate(PlyParams P, int n_plies, int32_t* actions_ring) {
+  __shared__ BoardLds<NW> L;
+  const int b = blockIdx.x;
+  if (b >= P.n) return;
+  Geo<NW> g;
+  geo_init(g);
+  constexpr int K = Geo<NW>::K;
+  BoardRec* rec = P.state + b;
+  Scalars s;
+  uint32_t lab[K], lastp[K];
+  Masks m;
+  Own<NW> o;
+  load_record(rec, L, g, lab, lastp, s, m);
+  own_from_masks(g, m, o);
+  float hv_none[K];
+  GO_UNROLL
+  for (int k = 0; k < K; ++k) hv_none[k] = 0.f;
+  for (int t = 0; t < n_plies; ++t) {  // host-supplied bound, the same for every wave
+    if (NW > 1) WSYNC();  // the previous ply's plane stores have taken their LDS operands
+    if (s.done) {
+      if (!s.counted) account_game(P.stats, g.tid, s, tromp_taylor(L, g, lab), P.komi);
+      restart_in_place(L, g, lab, lastp, s, m, o);
+    }
+    const int a = ply_body<NW, true>(L, g, lab, lastp, s, m, o, P, b, 0ll);
+    gather_masks(L, g, o, m);
+    const size_t row = (size_t)t * P.n + b;
+    if (actions_ring && g.tid == 0) actions_ring[row] = a;
+    if (P.legal) write_legal(g, o, P.legal + row * NPTS);
+    if (P.feat) {
+      const int aug = P.aug ? (P.aug[b] & 7) : 0;
+      write_features<NW, true, false>(L, g, lab, lastp, s, aug, P.lut, P.feat + row * GOENV_FEAT_FLOATS, hv_none, -1,
+                                      P.lut1);
+    }
+  }
+  store_board(rec, g, lab, lastp, o, s);
+}
+
 // Replay of given move lists (SGF records packed on the host): row b applies
 // moves[b*stride + 0 .. nmoves[b]) to its board with GoState::forward semantics and stops at the
 // first illegal move (go/offpolicy_loader.cc:120-126); napplied[b] = moves applied.  The board
@@ -971,6 +1013,20 @@ int goenv_playout(goenv_ctx* c, int16_t* moves_out, int max_record, int32_t* nmo
   if (moves_out && max_record <= 0) return fail("goenv_playout: max_record must be positive");
   PlyParams P = make_params(c, GOENV_F_RANDOM_POLICY, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   GO_LAUNCH(pick_nw(c, c->n), k_playout, c->n, S(stream), P, moves_out, max_record, nmoves_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* feat_ring, uint8_t* legal_ring,
+                   int32_t* actions_ring, void* stream) {
+  if (!c) return fail("goenv_generate: ctx is NULL");
+  if (n_plies < 0 || n_plies > (1 << 20)) return fail("goenv_generate: n_plies out of range");
+  if (n_plies == 0) return 0;
+  PlyParams P = make_params(c, GOENV_F_RANDOM_POLICY | GOENV_F_AUTO_RESTART, nullptr, aug_codes, feat_ring, legal_ring,
+                            nullptr, nullptr);
+  // persistent launch: boards drift apart, two waves per board hide the rest (tools/time_generate.py)
+  const int nw = c->nw ? c->nw : (c->n <= 4096 ? 2 : 3);
+  GO_LAUNCH(nw, k_generate, c->n, S(stream), P, n_plies, actions_ring);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -64,6 +64,7 @@ _SIGS = {
     "goenv_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "goenv_device_free": (C.c_int, [C.c_void_p]),
     "goenv_playout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "goenv_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goenv_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goenv_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
     "goenv_stats_ptr": (C.c_void_p, [C.c_void_p]),
@@ -277,6 +278,15 @@ class GoEnv:
             self._check(moves_out, torch.int16, (self.n, max_record), "moves_out")
         self._check(nmoves_out, torch.int32, (self.n,), "nmoves_out")
         self._chk(self.lib.goenv_playout(self._h, _ptr(moves_out), max_record, _ptr(nmoves_out), self._stream()))
+
+    def generate(self, n_plies, feat_ring=None, legal_ring=None, actions_ring=None, aug_codes=None):
+        """goenv_generate: n_plies plies in one persistent launch into [n_plies][n]... ring buffers."""
+        self._check(feat_ring, torch.float32, (n_plies, self.n, NUM_PLANES, 19, 19), "feat_ring")
+        self._check(legal_ring, torch.uint8, (n_plies, self.n, NUM_POINTS), "legal_ring")
+        self._check(actions_ring, torch.int32, (n_plies, self.n), "actions_ring")
+        self._check(aug_codes, torch.int32, (self.n,), "aug_codes")
+        self._chk(self.lib.goenv_generate(self._h, int(n_plies), _ptr(aug_codes), _ptr(feat_ring), _ptr(legal_ring),
+                                          _ptr(actions_ring), self._stream()))
 
     def score(self, score_out=None, fast_out=None):
         self._check(score_out, torch.float32, (self.n,), "score_out")

@@ -268,6 +268,17 @@ int goenv_host_free(void* p);
 int goenv_playout(goenv_ctx* ctx, int16_t* moves_out, int max_record, int32_t* nmoves_out,
                   void* stream);
 
+/* goenv_generate: n_plies plies of the on-device cfg-2 policy on EVERY board inside one
+ * persistent launch (finished games are scored, counted and restarted in place, as
+ * GOENV_F_AUTO_RESTART does), for callers without a model in the loop (random-playout data
+ * generation).  Ply t's outputs go to slot t of the caller's ring buffers:
+ * feat_ring float32 [n_plies][n][25][19][19], legal_ring u8 [n_plies][n][361], actions_ring
+ * int32 [n_plies][n]; any may be NULL.  Results equal n_plies calls of
+ * goenv_ply(RANDOM_POLICY | AUTO_RESTART).  aug_codes: int32 [n] or NULL.  No counterpart in
+ * the reference (its playouts run one thread per game on the CPU). */
+int goenv_generate(goenv_ctx* ctx, int n_plies, const int32_t* aug_codes, float* feat_ring,
+                   uint8_t* legal_ring, int32_t* actions_ring, void* stream);
+
 /* goenv_score: GetTrompTaylorScore(board, NULL, NULL) (go/board.cc:1584-1688)
  * into score_out float32 [n] (black minus white, no komi; 0 on an empty
  * board); fast_out (may be NULL) = GetFastScore(board, RULE_CHINESE)

@@ -165,3 +165,33 @@ def test_selections_and_sequencing_records(goenv):
     with pytest.raises(goenv.GoEnvError):
         env.collect_sel(first=10, count=10, feat_out=feat)
     env.close()
+
+
+def test_generate_equals_per_ply_launches(goenv):
+    """The persistent generator writes, slot by slot, exactly what the per-ply launches write
+    (moves, masks, planes), restarts included, and ends in the same state and statistics."""
+    B, T, seed = 48, 40, 21
+    rounds = 4                       # a low ply cap forces restarts inside the rings
+    a = goenv.GoEnv(B, seed=seed, max_ply=60)
+    b = goenv.GoEnv(B, seed=seed, max_ply=60)
+    dev = a.device
+    augs = (torch.arange(B, dtype=torch.int32, device=dev) % 8).contiguous()
+    feat_ring = torch.zeros(T, B, 25, 19, 19, device=dev)
+    legal_ring = torch.zeros(T, B, 361, dtype=torch.uint8, device=dev)
+    act_ring = torch.zeros(T, B, dtype=torch.int32, device=dev)
+    feat, legal, acts = b.new(torch.float32, 25, 19, 19), b.new(torch.uint8, 361), b.new(torch.int32)
+    flags = goenv.F_RANDOM_POLICY | goenv.F_AUTO_RESTART
+    for r in range(rounds):
+        a.generate(T, feat_ring, legal_ring, act_ring, aug_codes=augs)
+        for t in range(T):
+            b.ply(flags, aug_codes=augs, feat_out=feat, legal_out=legal, actions_out=acts)
+            assert torch.equal(act_ring[t], acts), (r, t)
+            assert torch.equal(legal_ring[t], legal), (r, t)
+            assert torch.equal(feat_ring[t].view(torch.int32), feat.view(torch.int32)), (r, t)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        x, y = (sa[k].view(torch.int16), sb[k].view(torch.int16)) if sa[k].dtype == torch.uint16 else (sa[k], sb[k])
+        assert torch.equal(x, y), k
+    assert a.stats() == b.stats() and a.stats()[goenv.ST_GAMES] > B
+    a.close()
+    b.close()
