@@ -844,6 +844,23 @@ PYBIND11_MODULE(go_game, m) {
     d["players"] = std::vector<int>(r.players.begin(), r.players.end());
     return d;
   });
+  m.def("corpus_names", [](const std::string& list_or_tar) {   // what OfflineLoader::InitSharedBuffer lists
+    SgfCorpus c;
+    c.load_list(list_or_tar);
+    std::vector<std::string> v;
+    for (size_t i = 0; i < c.size(); ++i) v.push_back(c.name(i));
+    return v;
+  });
+  m.def("corpus_record", [](const std::string& list_or_tar, size_t i) {
+    SgfCorpus c;
+    py::dict d;
+    if (!c.load_list(list_or_tar) || i >= c.size()) return d;
+    const SgfRecord& r = c.get(i);
+    d["ok"] = r.ok; d["num_moves"] = r.num_moves; d["handi"] = r.handi; d["winner"] = r.winner;
+    d["board_size"] = r.board_size;
+    d["moves"] = std::vector<int>(r.moves.begin(), r.moves.end());
+    return d;
+  });
   m.def("aug_action", &goenv_aug_action);        // BoardFeature::Coord2Action, go/board_feature.h:62-65
   m.def("aug_action_inv", &goenv_aug_action_inv);  // BoardFeature::Action2Coord, :67-71
 }

@@ -9,6 +9,7 @@
 // forward() (batched by the GameContext into one goenv_ply_sel launch) and Extract.
 #pragma once
 
+#include <cstring>
 #include <map>
 #include <memory>
 #include <random>
@@ -33,7 +34,16 @@ struct OfflineOptions {
 // elf/shared_replay_buffer.h): list file -> names; records parsed on first use.
 class SgfCorpus {
  public:
+  // elf::tar::file_is_tar, elf/tar_loader.cc:16-18
+  static bool is_tar(const std::string& filename) {
+    return filename.substr(filename.find_last_of(".") + 1) == "tar";
+  }
+
   bool load_list(const std::string& list_filename) {
+    names_.clear();
+    cache_.clear();
+    tar_.clear();
+    if (is_tar(list_filename)) return load_tar(list_filename);
     std::ifstream f(list_filename);
     if (!f.is_open()) return false;
     names_.clear();
@@ -48,15 +58,60 @@ class SgfCorpus {
   const SgfRecord& get(size_t i) {
     auto it = cache_.find(i);
     if (it == cache_.end()) {
-      it = cache_.emplace(i, std::unique_ptr<SgfRecord>(new SgfRecord(load_sgf_file(dir_ + names_[i])))).first;
+      SgfRecord rec = tar_.empty() ? load_sgf_file(dir_ + names_[i]) : parse_sgf(tar_member(names_[i]));
+      it = cache_.emplace(i, std::unique_ptr<SgfRecord>(new SgfRecord(std::move(rec)))).first;
     }
     return *it->second;
   }
 
+  // TarLoader::Load (elf/tar_loader.cc:32-41): the first member of that name, cut at its first NUL
+  std::string tar_member(const std::string& name) const {
+    for (const TarEntry& e : entries_)
+      if (e.name == name) {
+        std::string text = tar_.substr(e.offset, e.size);
+        const size_t nul = text.find('\0');
+        return nul == std::string::npos ? text : text.substr(0, nul);
+      }
+    return std::string();
+  }
+
  private:
+  struct TarEntry {
+    std::string name;
+    size_t offset, size;
+  };
   std::vector<std::string> names_;
   std::string dir_;
   std::map<size_t, std::unique_ptr<SgfRecord>> cache_;
+  std::string tar_;               // whole archive (SGF corpora are small text)
+  std::vector<TarEntry> entries_;
+
+  // TarLoader::List (elf/tar_loader.cc:24-31): every 512-byte header in archive order, whatever
+  // its type, until the null record (vendor microtar reads name at 0, octal size at 124 and stops
+  // at a header whose checksum field starts with NUL).
+  bool load_tar(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) return false;
+    std::stringstream ss;
+    ss << f.rdbuf();
+    tar_ = ss.str();
+    entries_.clear();
+    size_t pos = 0;
+    while (pos + 512 <= tar_.size()) {
+      const char* h = tar_.data() + pos;
+      if (h[148] == '\0') break;
+      TarEntry e;
+      e.name = std::string(h, strnlen(h, 100));
+      e.size = (size_t)std::strtoul(std::string(h + 124, 12).c_str(), nullptr, 8);
+      e.offset = pos + 512;
+      if (e.offset + e.size > tar_.size()) break;
+      entries_.push_back(e);
+      names_.push_back(e.name);
+      pos = e.offset + ((e.size + 511) / 512) * 512;
+    }
+    if (tar_.empty()) tar_.assign(1, '\0');  // marks "tar mode" even for an empty archive
+    return !names_.empty();
+  }
 };
 
 // One replay: a record, a position in it and a board on the device.

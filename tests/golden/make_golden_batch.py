@@ -100,6 +100,16 @@ def make_corpus():
         f.write("\n".join(names) + "\n")
     with open(os.path.join(CORPUS, "one.lst"), "w") as f:
         f.write("sample1.sgf\n")
+    # the same corpus as a tar archive (OfflineLoader::InitSharedBuffer takes either,
+    # go/offpolicy_loader.cc:27-30); plain ustar headers, members in list order, fixed metadata
+    import tarfile
+    tar_path = os.path.join(CORPUS, "corpus.tar")
+    with tarfile.open(tar_path, "w", format=tarfile.USTAR_FORMAT) as tf:
+        for nm in names:
+            ti = tf.gettarinfo(os.path.join(CORPUS, nm), arcname=nm)
+            ti.mtime, ti.uid, ti.gid, ti.uname, ti.gname, ti.mode = 0, 0, 0, "", "", 0o644
+            with open(os.path.join(CORPUS, nm), "rb") as f:
+                tf.addfile(ti, f)
     return names
 
 
@@ -110,6 +120,8 @@ RUNS = [
          cutoff=70, k=3, samples=400, lst="train.lst"),
     dict(name="k5_aug6", seed=99, num_games=2, games_per_thread=2, data_aug=6, start_ratio=0.2, ratio=0.2,
          cutoff=-1, k=5, samples=300, lst="train.lst"),
+    dict(name="tar_corpus", seed=31, num_games=2, games_per_thread=2, data_aug=-1, start_ratio=0.5, ratio=0.2,
+         cutoff=-1, k=3, samples=300, lst="corpus.tar"),
     dict(name="multi_game_one_file", seed=2024, num_games=3, games_per_thread=3, data_aug=-1, start_ratio=0.5,
          ratio=0.1, cutoff=-1, k=3, samples=200, lst="one.lst"),
 ]
@@ -219,8 +231,13 @@ def main():
     for i, cfg in enumerate(RUNS):
         with tempfile.TemporaryDirectory() as td:
             tmp = os.path.join(td, "run.json")
-            subprocess.run([sys.executable, os.path.abspath(__file__), "--run", str(i), tmp], check=True,
-                           stdout=subprocess.DEVNULL, timeout=600)
+            for attempt in range(4):   # the reference's thread teardown occasionally crashes the child
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--run", str(i), tmp],
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+                if r.returncode == 0 and os.path.exists(tmp):
+                    break
+            else:
+                raise SystemExit("reference run %d failed" % i)
             with open(tmp) as f:
                 st = json.load(f)
         out["runs"].append(dict(cfg=cfg, streams=st))

@@ -145,3 +145,16 @@ def test_aug_action_tables_match_golden(go):
     for code in range(8):
         assert [go.aug_action(code, a) for a in range(361)] == d4["coord2action"][code]
         assert [go.aug_action_inv(code, a) for a in range(361)] == d4["action2coord"][code]
+
+
+def test_tar_corpus_lists_and_reads_like_the_list_file(go):
+    """OfflineLoader::InitSharedBuffer takes a list file or a tar archive (go/offpolicy_loader.cc:27-50)."""
+    tar = os.path.join(GOLDEN, "corpus", "corpus.tar")
+    lst = os.path.join(GOLDEN, "corpus", "train.lst")
+    names = go.corpus_names(lst)
+    assert names == go.corpus_names(tar) == load_golden("batch_streams.json")["corpus"]
+    ref = load_golden("corpus_parse.json")
+    for i, nm in enumerate(names):
+        a, b = go.corpus_record(tar, i), go.corpus_record(lst, i)
+        assert a == b and a["moves"] == ref[nm]["moves"] and a["num_moves"] == ref[nm]["num_moves"], nm
+    assert go.corpus_names(os.path.join(GOLDEN, "corpus", "missing.tar")) == []
