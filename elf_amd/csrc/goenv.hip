@@ -120,7 +120,7 @@ __device__ __forceinline__ void emit_sample_meta(const goenv_sample_out& o, int 
 // One ply for one board held in LDS/registers.  `m` = masks of the position (all words), `o`
 // receives this wave's words of the NEW position's masks.  Returns the action applied (-1 pass)
 // or -4 if the external action was illegal (state and `o` untouched).
-template <int NW, bool RANDOM>
+template <int NW, bool RANDOM, bool MASKS = true>
 __device__ __forceinline__ int ply_body(BoardLds<NW>& L, const Geo<NW>& g, uint32_t lab[], uint32_t lastp[],
                                         Scalars& s, const Masks& m, Own<NW>& o, const PlyParams& P, int board,
                                         long long av) {
@@ -147,7 +147,7 @@ __device__ __forceinline__ int ply_body(BoardLds<NW>& L, const Geo<NW>& g, uint3
     apply_move(L, g, lab, lastp, s, a, s.next);
   }
   STAMP(3);
-  move_masks(L, g, lab, s, s.next, o);
+  if (MASKS) move_masks(L, g, lab, s, s.next, o);
   s.done = game_end(s) ? 1 : ((P.max_ply > 0 && s.ply > P.max_ply) ? 2 : 0);
   s.counted = 0;
   return a;
@@ -196,40 +196,47 @@ __global__ __launch_bounds__(64 * NW) void k_ply(PlyParams P) {
   }
   int a = -3, status = -1;
   if (!skip) {
-    a = ply_body<NW, RANDOM>(L, g, lab, lastp, s, m, o, P, board, RANDOM ? 0ll : (long long)P.actions[b]);
+    // the masks of the new position are computed AFTER the planes have been issued: the plane
+    // stores then drain to HBM while the workgroup finishes its mask / record tail
+    a = ply_body<NW, RANDOM, false>(L, g, lab, lastp, s, m, o, P, board, RANDOM ? 0ll : (long long)P.actions[b]);
     status = (a == -4) ? 0 : 1;
+    bool fresh = false;  // restarted: `o` already holds the masks of the empty board
     if (a == -4 && (P.flags & GOENV_F_RESET_ILLEGAL)) {
       // "No valid move ..., restarting the game", go/game.cc:81-90
       restart_in_place(L, g, lab, lastp, s, m, o);
+      fresh = true;
     } else if (a != -4 && s.done && (P.flags & GOENV_F_RESTART_AFTER_END)) {
       account_game(P.stats, g.tid, s, tromp_taylor(L, g, lab), P.komi);
       restart_in_place(L, g, lab, lastp, s, m, o);
       status = 2;
+      fresh = true;
     }
     STAMP(4);
     const int aug = P.aug ? (P.aug[b] & 7) : 0;
+    const int ply_of_sample = s.ply;
     if (P.flags & GOENV_F_COLLECT) emit_sample_meta(P.meta, b, board, g.tid, s, aug);
+    (void)ply_of_sample;
+    if (P.feat) {
+      float* out = P.feat + (size_t)b * GOENV_FEAT_FLOATS;
+      switch (P.zero_first & 3) {
+        case 0: write_features<NW, true, false>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
+        case 1: write_features<NW, false, false>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
+        case 2: write_features<NW, true, true>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
+        default: write_features<NW, false, true>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
+      }
+    }
+    STAMP(5);
+    if (a != -4 && !fresh) move_masks(L, g, lab, s, s.next, o);
+    STAMP(6);
     if (a != -4 || (P.flags & (GOENV_F_RESET_ILLEGAL | GOENV_F_COLLECT)))
       store_board(rec, g, lab, lastp, o, s);
   }
-  STAMP(5);
   if (g.tid == 0) {
     if (P.actions_out) P.actions_out[b] = a;
     if (P.status) P.status[b] = status;
   }
   if (skip) return;
   if (P.legal) write_legal(g, o, P.legal + (size_t)b * NPTS);
-  STAMP(6);
-  if (P.feat) {
-    const int aug = P.aug ? (P.aug[b] & 7) : 0;
-    float* out = P.feat + (size_t)b * GOENV_FEAT_FLOATS;
-    switch (P.zero_first & 3) {
-      case 0: write_features<NW, true, false>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
-      case 1: write_features<NW, false, false>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
-      case 2: write_features<NW, true, true>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
-      default: write_features<NW, false, true>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
-    }
-  }
   STAMP(7);
 }
 
@@ -718,13 +725,12 @@ static int pick_zero_first(const goenv_ctx* c, int count) {
 
 // Waves per board of a launch over `count` boards.  Small launches are bound by the dependent
 // chain of one board, which more waves per board shorten (1,024 boards: 17.4 us with one wave,
-// 13.2 us with three); large ones are HBM-bound and still gain a few percent from two or three
-// waves sharing the plane stores of a board.
+// 13.2 us with three); large ones are HBM-bound and still gain from three waves sharing the plane
+// stores of a board (65,536 boards: 585 us with two waves, 492 us with three).
 static int pick_nw(const goenv_ctx* c, int count) {
   if (c->nw) return c->nw;   // measured: tools/tune_waves.py, profiles/r01_tune_waves.txt
   if (count <= 512) return 6;
-  if (count <= 12288) return 3;
-  return 2;
+  return 3;
 }
 
 static thread_local std::string g_err;

@@ -364,12 +364,17 @@ __device__ __forceinline__ bool is_stone(uint32_t v) { uint32_t c = col_of(v); r
 // (== the distinct-liberty count RecomputeGroupLiberties produces, go/board.cc:595-620), then
 // every stone's cls bits are refreshed to min(liberties, 3).  Branch-free: masked-off adds go to
 // a per-thread sink slot.
-template <int NW>
-__device__ __forceinline__ void rebuild_lib(BoardLds<NW>& L, const Geo<NW>& g, uint32_t lab[]) {
-  GO_UNROLL
-  for (int k = 0; k < Geo<NW>::K; ++k)
-    if (g.p[k] < NPTS) L.lib[g.p[k]] = 0;
-  WSYNC();
+// PREZEROED: the caller cleared lib[0..360] before its own last barrier.  Returns the liberty
+// count of root `probe` (-1: none), read before the closing barrier so that the table is dead
+// once this function returns (write_features reuses it without another barrier).
+template <int NW, bool PREZEROED = false>
+__device__ __forceinline__ int rebuild_lib(BoardLds<NW>& L, const Geo<NW>& g, uint32_t lab[], int probe = -1) {
+  if (!PREZEROED) {
+    GO_UNROLL
+    for (int k = 0; k < Geo<NW>::K; ++k)
+      if (g.p[k] < NPTS) L.lib[g.p[k]] = 0;
+    WSYNC();
+  }
   const int sink = TAB_N + g.tid;
   GO_UNROLL
   for (int k = 0; k < Geo<NW>::K; ++k) {
@@ -399,7 +404,9 @@ __device__ __forceinline__ void rebuild_lib(BoardLds<NW>& L, const Geo<NW>& g, u
       L.lab[g.c[k]] = (uint16_t)v;
     }
   }
+  const int probed = probe >= 0 ? (int)L.lib[probe] : 0;
   WSYNC();
+  return __builtin_amdgcn_readfirstlane(probed);
 }
 
 // 16-entry truth tables over typ = colour | cls<<2 of a neighbour.
@@ -514,6 +521,7 @@ __device__ __forceinline__ void apply_move(BoardLds<NW>& L, const Geo<NW>& g, ui
     const unsigned long long m = __ballot(cap);
     if (m) { total_capture += popc64(m); capture_p = 64 * (NW * k + g.wave) + (int)__builtin_ctzll(m); }
     if (v != lab[k]) { L.lab[g.c[k]] = (uint16_t)v; lab[k] = v; }
+    if (g.p[k] < NPTS) L.lib[g.p[k]] = 0;  // liberty table cleared under the same barrier
   }
   if (NW > 1 && g.lane == 0) L.xcap[g.wave] = (uint32_t)total_capture | ((uint32_t)(capture_p + 1) << 16);
   WSYNC();
@@ -527,9 +535,9 @@ __device__ __forceinline__ void apply_move(BoardLds<NW>& L, const Geo<NW>& g, ui
     }
   }
   if (player == S_BLACK) s.bcap += total_capture; else s.wcap += total_capture;  // board.cc:1132-1133
-  rebuild_lib(L, g, lab);
+  const int new_libs = rebuild_lib<NW, true>(L, g, lab, p);
   // simple ko, board.cc:1163-1171
-  if (!merged && total_capture == 1 && L.lib[p] == 1) {
+  if (!merged && total_capture == 1 && new_libs == 1) {
     s.ko = capture_p; s.kocolor = (int)opp; s.koage = 0;
   } else {
     s.koage = (s.koage + 1) & 0xffff;
@@ -646,37 +654,27 @@ __device__ __forceinline__ int fast_score_cn(BoardLds<NW>& L, const Geo<NW>& g, 
   return board_sum(L, g, sc, 1);
 }
 
-// Colour ballots of the whole board in every wave: wb/ww[0..5], [6] = 0.
-template <int NW>
-__device__ __forceinline__ void colour_words(BoardLds<NW>& L, const Geo<NW>& g, const uint32_t lab[],
-                                             unsigned long long wb[NWORDS + 1], unsigned long long ww[NWORDS + 1]) {
-  constexpr int K = Geo<NW>::K;
-  if (NW == 1) {
-    GO_UNROLL
-    for (int k = 0; k < K; ++k) {
-      wb[k] = __ballot(col_of(lab[k]) == 1);
-      ww[k] = __ballot(col_of(lab[k]) == 2);
-    }
-  } else {
-    GO_UNROLL
-    for (int k = 0; k < K; ++k) {
-      const unsigned long long b = __ballot(col_of(lab[k]) == 1), w = __ballot(col_of(lab[k]) == 2);
-      if (g.lane == 0) { L.xcol[NW * k + g.wave] = b; L.xcol[NWORDS + NW * k + g.wave] = w; }
-    }
-    WSYNC();
-    GO_UNROLL
-    for (int j = 0; j < NWORDS; ++j) { wb[j] = uni64(L.xcol[j]); ww[j] = uni64(L.xcol[NWORDS + j]); }
-  }
-  wb[NWORDS] = 0; ww[NWORDS] = 0;
+// BoardFeature::Transform (go/board_feature.h:38-48): output index of point p under a D4 code.
+__device__ __forceinline__ int d4_dest(int code, int p) {
+  const int x = p / BS, y = p - x * BS;
+  const int rot = code & 3;
+  int ox, oy;
+  if (rot == 1) { ox = y; oy = BS - 1 - x; }
+  else if (rot == 2) { ox = BS - 1 - x; oy = BS - 1 - y; }
+  else if (rot == 3) { ox = BS - 1 - y; oy = x; }
+  else { ox = x; oy = y; }
+  if ((code >> 2) == 1) { const int t = ox; ox = oy; oy = t; }
+  return ox * BS + oy;
 }
 
 // Exact L1 distance to the nearest black / white stone (GetDistanceMap + DistanceTransform,
 // go/board_feature.cc:17-38,148-160) into L.dist, by ONE wave (lanes = (colour, y) lines).
 // Pass 1 (along y) is a bit trick on the 19-bit column occupancy, pass 2 (along x) the
 // reference's forward/backward min-plus sweep, fully unrolled in registers.
+// Results are stored at the OUTPUT index of each point (D4 code `aug` applied here).
 template <int NW>
 __device__ __forceinline__ void distance_lines(BoardLds<NW>& L, int lane, const unsigned long long wb[NWORDS + 1],
-                                               const unsigned long long ww[NWORDS + 1]) {
+                                               const unsigned long long ww[NWORDS + 1], int aug) {
   const bool white_lane = lane >= 32;
   const int y = lane & 31;
   int a[BS];
@@ -698,22 +696,14 @@ __device__ __forceinline__ void distance_lines(BoardLds<NW>& L, int lane, const 
   for (int x = BS - 2; x >= 0; --x) a[x] = min(a[x], a[x + 1] + 1);
   if (y < BS) {
     uint8_t* d = L.dist[white_lane ? 1 : 0];
-    GO_UNROLL
-    for (int x = 0; x < BS; ++x) d[x * BS + y] = (uint8_t)a[x];
+    if (aug == 0) {
+      GO_UNROLL
+      for (int x = 0; x < BS; ++x) d[x * BS + y] = (uint8_t)a[x];
+    } else {
+      GO_UNROLL
+      for (int x = 0; x < BS; ++x) d[d4_dest(aug, x * BS + y)] = (uint8_t)a[x];
+    }
   }
-}
-
-// BoardFeature::Transform (go/board_feature.h:38-48): output index of point p under a D4 code.
-__device__ __forceinline__ int d4_dest(int code, int p) {
-  const int x = p / BS, y = p - x * BS;
-  const int rot = code & 3;
-  int ox, oy;
-  if (rot == 1) { ox = y; oy = BS - 1 - x; }
-  else if (rot == 2) { ox = BS - 1 - x; oy = BS - 1 - y; }
-  else if (rot == 3) { ox = BS - 1 - y; oy = x; }
-  else { ox = x; oy = y; }
-  if ((code >> 2) == 1) { const int t = ox; ox = oy; oy = t; }
-  return ox * BS + oy;
 }
 
 // 4 floats with only 4-byte alignment: planes start every 1444 B and boards every 36100 B, so
@@ -801,28 +791,37 @@ __device__ __forceinline__ void write_features(BoardLds<NW>& L, const Geo<NW>& g
       else hv[k] = lut[age];
     }
   }
+  // colour ballots (published for the other waves) and the per-point descriptor, scattered to its
+  // OUTPUT index (D4 applied here): colour(2) | cls(2) | ko(1); history value in a parallel table
+  // (the liberty table is dead).  One barrier covers both.
   unsigned long long wb[NWORDS + 1], ww[NWORDS + 1];
-  colour_words(L, g, lab, wb, ww);
-  int has = 0;
-  GO_UNROLL
-  for (int j = 0; j < NWORDS; ++j) { if (wb[j]) has |= 1; if (ww[j]) has |= 2; }
-  const int ko_p = (s.koage == 0 && s.ko >= 0) ? s.ko : -1;  // GetSimpleKoLocation, board.cc:337-344
-  // per-point descriptor, scattered to its OUTPUT index (D4 applied here):
-  //   colour(2) | cls(2) | ko(1);  history value in a parallel table (the liberty table is dead)
-  float* hist = reinterpret_cast<float*>(L.lib);
-  int q[K];
   GO_UNROLL
   for (int k = 0; k < K; ++k) {
-    q[k] = 0;
+    const unsigned long long bb = __ballot(col_of(lab[k]) == 1), bw = __ballot(col_of(lab[k]) == 2);
+    if (NW == 1) { wb[k] = bb; ww[k] = bw; }
+    else if (g.lane == 0) { L.xcol[NW * k + g.wave] = bb; L.xcol[NWORDS + NW * k + g.wave] = bw; }
+  }
+  const int ko_p = (s.koage == 0 && s.ko >= 0) ? s.ko : -1;  // GetSimpleKoLocation, board.cc:337-344
+  float* hist = reinterpret_cast<float*>(L.lib);
+  GO_UNROLL
+  for (int k = 0; k < K; ++k) {
     if (g.p[k] < NPTS) {
       uint32_t d = typ_of(lab[k]);  // cls 1,2,3 <-> GetLibertyMap3binary :83-99
       if (g.p[k] == ko_p) d |= 16u;
-      q[k] = aug ? d4_dest(aug, g.p[k]) : g.p[k];
-      L.desc[q[k]] = d;
-      hist[q[k]] = hv[k];
+      const int q = aug ? d4_dest(aug, g.p[k]) : g.p[k];
+      L.desc[q] = d;
+      hist[q] = hv[k];
     }
   }
   WSYNC();
+  if (NW > 1) {
+    GO_UNROLL
+    for (int j = 0; j < NWORDS; ++j) { wb[j] = uni64(L.xcol[j]); ww[j] = uni64(L.xcol[NWORDS + j]); }
+  }
+  wb[NWORDS] = 0; ww[NWORDS] = 0;
+  int has = 0;
+  GO_UNROLL
+  for (int j = 0; j < NWORDS; ++j) { if (wb[j]) has |= 1; if (ww[j]) has |= 2; }
   const uint32_t our = (uint32_t)s.next, opp = 3u - our;
   const bool has_our = (has >> (our - 1)) & 1, has_opp = (has >> (opp - 1)) & 1;
   const int qa = 4 * lane;
@@ -885,19 +884,20 @@ __device__ __forceinline__ void write_features(BoardLds<NW>& L, const Geo<NW>& g
       if (5 % NS == sw) zero_range<WT>(out + 20 * NPTS, 5 * NPTS, lane);
     }
   }
-  if (g.wave == 0) distance_lines(L, lane, wb, ww);
+  if (g.wave == 0) distance_lines(L, lane, wb, ww, aug);
   WSYNC();
-  // distances to the output index, packed into the (now free) descriptor table
-  GO_UNROLL
-  for (int k = 0; k < K; ++k)
-    if (g.p[k] < NPTS) L.desc[q[k]] = (uint32_t)L.dist[0][g.p[k]] | ((uint32_t)L.dist[1][g.p[k]] << 8);
-  WSYNC();
-  const int sh_our = our == 1 ? 0 : 8, sh_opp = our == 1 ? 8 : 0;
+  // planes 14 / 15 straight from the distance tables (already in output order)
   if (g.wave == 0 || (NW > 1 && g.wave == 1)) {
-    GO_UNROLL
-    for (int i = 0; i < 4; ++i) { d[i] = L.desc[qa + i]; d[4 + i] = L.desc[qb + i]; h[i] = 0.f; h[4 + i] = 0.f; }
-    if (g.wave == 0) GO_PLANE(14, has_our ? (float)((dd >> sh_our) & 255u) : 10000.f);
-    if (NW == 1 || g.wave == 1) GO_PLANE(15, has_opp ? (float)((dd >> sh_opp) & 255u) : 10000.f);
+    const bool second = NW > 1 && g.wave == 1;                       // wave 1 takes plane 15
+    for (int pass = 0; pass < (NW == 1 ? 2 : 1); ++pass) {
+      const bool opp_plane = second || pass == 1;
+      const uint8_t* dt = L.dist[(opp_plane ? opp : our) - 1];
+      const bool present = opp_plane ? has_opp : has_our;
+      GO_UNROLL
+      for (int i = 0; i < 4; ++i) { d[i] = dt[qa + i]; d[4 + i] = dt[qb + i]; h[i] = 0.f; h[4 + i] = 0.f; }
+      if (opp_plane) GO_PLANE(15, present ? (float)dd : 10000.f);
+      else GO_PLANE(14, present ? (float)dd : 10000.f);
+    }
   }
 #undef GO_PLANE
 }
