@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64) void k_sample_policy(const BoardRec* state, int
 }
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_score(const BoardRec* state, int n, float* tt, float* fast) {
+__global__ __launch_bounds__(64 * NW) void k_score(const BoardRec* state, int n, float* tt, float* fast, int rule) {
   __shared__ BoardLds<NW> L;
   const int b = blockIdx.x;
   if (b >= n) return;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64 * NW) void k_score(const BoardRec* state, int n,
   uint32_t lab[K], lastp[K];
   load_board(rec, L, g, lab, lastp);
   if (fast) {
-    int f = fast_score_cn(L, g, lab, s);
+    int f = fast_score(L, g, lab, s, rule);
     if (g.tid == 0) fast[b] = (float)f;
   }
   if (tt) {
@@ -1039,7 +1039,15 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
 
 int goenv_score(goenv_ctx* c, float* score_out, float* fast_out, void* stream) {
   if (!c) return fail("goenv_score: ctx is NULL");
-  GO_LAUNCH(pick_nw(c, c->n), k_score, c->n, S(stream), c->state, c->n, score_out, fast_out);
+  GO_LAUNCH(pick_nw(c, c->n), k_score, c->n, S(stream), c->state, c->n, score_out, fast_out, 0);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int goenv_fast_score(goenv_ctx* c, int rule, float* out, void* stream) {
+  if (!c || !out) return fail("goenv_fast_score: NULL argument");
+  if (rule != 0 && rule != 1) return fail("goenv_fast_score: rule must be 0 (Chinese) or 1 (Japanese)");
+  GO_LAUNCH(pick_nw(c, c->n), k_score, c->n, S(stream), c->state, c->n, (float*)nullptr, out, rule);
   HIPCHK(hipGetLastError());
   return 0;
 }

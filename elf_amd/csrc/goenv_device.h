@@ -636,11 +636,13 @@ __device__ __forceinline__ int tromp_taylor(BoardLds<NW>& L, const Geo<NW>& g, c
   return board_sum(L, g, diff, 0);
 }
 
-// GetFastScore(board, RULE_CHINESE), go/board.cc:1560-1582: stones + true eyes per colour
-// (GetEyeColor tests white first, :1554-1558).
+// GetFastScore, go/board.cc:1560-1582 (GetEyeColor tests white first, :1554-1558).
+// rule 0 = RULE_CHINESE: stones + true eyes per colour; rule 1 = RULE_JAPANESE: true eyes +
+// captures (`_rollout_passes` is 0 on every path that reaches this build: only the reference's
+// own CPU rollouts change it).  Both are narrowed to `short` like the reference.
 template <int NW>
-__device__ __forceinline__ int fast_score_cn(BoardLds<NW>& L, const Geo<NW>& g, const uint32_t lab[],
-                                             const Scalars& s) {
+__device__ __forceinline__ int fast_score(BoardLds<NW>& L, const Geo<NW>& g, const uint32_t lab[],
+                                          const Scalars& s, int rule) {
   Own<NW> ob, ow;
   move_masks(L, g, lab, s, S_BLACK, ob);
   move_masks(L, g, lab, s, S_WHITE, ow);
@@ -648,10 +650,12 @@ __device__ __forceinline__ int fast_score_cn(BoardLds<NW>& L, const Geo<NW>& g, 
   GO_UNROLL
   for (int k = 0; k < Geo<NW>::K; ++k) {
     const uint32_t col = col_of(lab[k]);
-    sc += popc64(__ballot(col == 1)) + popc64(ob.eye[k] & ~ow.eye[k]);
-    sc -= popc64(__ballot(col == 2)) + popc64(ow.eye[k]);
+    sc += popc64(ob.eye[k] & ~ow.eye[k]) - popc64(ow.eye[k]);
+    if (rule == 0) sc += popc64(__ballot(col == 1)) - popc64(__ballot(col == 2));
   }
-  return board_sum(L, g, sc, 1);
+  sc = board_sum(L, g, sc, 1);
+  if (rule != 0) sc += s.bcap - s.wcap;
+  return (int)(short)sc;
 }
 
 // BoardFeature::Transform (go/board_feature.h:38-48): output index of point p under a D4 code.

@@ -66,6 +66,7 @@ _SIGS = {
     "goenv_playout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "goenv_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goenv_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "goenv_fast_score": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "goenv_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
     "goenv_stats_ptr": (C.c_void_p, [C.c_void_p]),
     "goenv_stats_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
@@ -292,6 +293,10 @@ class GoEnv:
         self._check(score_out, torch.float32, (self.n,), "score_out")
         self._check(fast_out, torch.float32, (self.n,), "fast_out")
         self._chk(self.lib.goenv_score(self._h, _ptr(score_out), _ptr(fast_out), self._stream()))
+
+    def fast_score(self, rule, out):
+        self._check(out, torch.float32, (self.n,), "out")
+        self._chk(self.lib.goenv_fast_score(self._h, int(rule), _ptr(out), self._stream()))
 
     def finish(self):
         self._chk(self.lib.goenv_finish(self._h, self._stream()))

@@ -284,6 +284,9 @@ int goenv_generate(goenv_ctx* ctx, int n_plies, const int32_t* aug_codes, float*
  * board); fast_out (may be NULL) = GetFastScore(board, RULE_CHINESE)
  * (go/board.cc:1560-1582). */
 int goenv_score(goenv_ctx* ctx, float* score_out, float* fast_out, void* stream);
+/* goenv_fast_score: GetFastScore(board, rule) (go/board.cc:1560-1582) into out float32 [n];
+ * rule 0 = RULE_CHINESE, 1 = RULE_JAPANESE. */
+int goenv_fast_score(goenv_ctx* ctx, int rule, float* out, void* stream);
 
 /* Statistics ---------------------------------------------------------------
  * goenv_finish: score every finished board that has not been counted yet and

@@ -118,8 +118,10 @@ def test_random_policy_playouts_ply_by_ply(goenv):
         assert seqs[game["board_id"]] == game["moves"]
     sc, fs = env.new(torch.float32), env.new(torch.float32)
     env.score(sc, fs)
+    jp = env.new(torch.float32)
+    env.fast_score(1, jp)
     for b, o in enumerate(oracles):
-        assert sc[b].item() == o.tt_score() and fs[b].item() == o.fast_score(0)
+        assert sc[b].item() == o.tt_score() and fs[b].item() == o.fast_score(0) and jp[b].item() == o.fast_score(1)
     # end-of-episode statistics
     env.finish()
     stats = env.stats()
