@@ -654,6 +654,19 @@ __global__ __launch_bounds__(64 * NW) void k_replay(PlyParams P, const int16_t* 
   if (napplied && g.tid == 0) napplied[b] = cnt;
 }
 
+// Record copies between slots of one context: what a host-side tree search needs to branch
+// (child slot = copy of the parent slot, then one goenv_ply_sel on the children).
+__global__ __launch_bounds__(128) void k_copy_boards(BoardRec* state, int n_total, const int32_t* src,
+                                                     const int32_t* dst, int n) {
+  const int b = blockIdx.x;
+  if (b >= n) return;
+  const int from = src[b], to = dst[b];
+  if (from < 0 || from >= n_total || to < 0 || to >= n_total || from == to) return;
+  const uint4* in = reinterpret_cast<const uint4*>(state + from);
+  uint4* out = reinterpret_cast<uint4*>(state + to);
+  for (int i = threadIdx.x; i < (int)(sizeof(BoardRec) / 16); i += blockDim.x) out[i] = in[i];
+}
+
 // Launch of a kernel template on the waves-per-board count chosen for this call.
 #define GO_LAUNCH(NWSEL, KERNEL, GRID, STREAM, ...)                                                  \
   do {                                                                                               \
@@ -998,6 +1011,16 @@ int goenv_replay(goenv_ctx* c, const int32_t* idx, int first, int count, const i
   P.n = count; P.idx = idx; P.first = first;
   P.max_ply = 0;  // a replayed record is not subject to the playout ply cap
   GO_LAUNCH(pick_nw(c, count), k_replay, count, S(stream), P, moves, stride, nmoves, napplied_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int goenv_copy_boards(goenv_ctx* c, const int32_t* src_idx, const int32_t* dst_idx, int n, void* stream) {
+  if (!c) return fail("goenv_copy_boards: ctx is NULL");
+  if (n < 0 || n > c->n) return fail("goenv_copy_boards: n out of range");
+  if (n == 0) return 0;
+  if (!src_idx || !dst_idx) return fail("goenv_copy_boards: src_idx and dst_idx are required");
+  hipLaunchKernelGGL(k_copy_boards, dim3(n), dim3(128), 0, S(stream), c->state, c->n, src_idx, dst_idx, n);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -58,6 +58,7 @@ _SIGS = {
                                C.c_void_p]),
     "goenv_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "goenv_host_free": (C.c_int, [C.c_void_p]),
+    "goenv_copy_boards": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "goenv_pointer_is_device": (C.c_int, [C.c_void_p]),
     "goenv_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "goenv_sync": (C.c_int, [C.c_void_p]),
@@ -271,6 +272,12 @@ class GoEnv:
         self._check(napplied_out, torch.int32, (count,), "napplied_out")
         self._chk(self.lib.goenv_replay(self._h, ip, first, count, _ptr(moves), moves.shape[1], _ptr(nmoves),
                                         _ptr(napplied_out), self._stream()))
+
+    def copy_boards(self, src_idx, dst_idx):
+        n = src_idx.numel()
+        self._check(src_idx, torch.int32, (n,), "src_idx")
+        self._check(dst_idx, torch.int32, (n,), "dst_idx")
+        self._chk(self.lib.goenv_copy_boards(self._h, _ptr(src_idx), _ptr(dst_idx), n, self._stream()))
 
     def playout(self, moves_out=None, nmoves_out=None):
         max_record = 0

@@ -247,6 +247,14 @@ int goenv_get_state_sel(goenv_ctx* ctx, const int32_t* idx, int first, int count
 int goenv_replay(goenv_ctx* ctx, const int32_t* idx, int first, int count, const int16_t* moves,
                  int stride, const int32_t* nmoves, int32_t* napplied_out, void* stream);
 
+/* goenv_copy_boards: board dst_idx[i] becomes a copy of board src_idx[i] (device int32 [n];
+ * the destinations must be distinct and must not appear among the sources of the same call).
+ * This is CopyBoard (go/board.h, used by GoState's copy constructor go/go_state.h:47-49) for
+ * callers that branch positions, e.g. a host-side tree search evaluating its leaves in device
+ * batches. */
+int goenv_copy_boards(goenv_ctx* ctx, const int32_t* src_idx, const int32_t* dst_idx, int n,
+                      void* stream);
+
 /* Memory helpers for hosts that do not link the HIP runtime themselves (the
  * GameContext layer): pointer classification (EntryInfo.p may be host or
  * device, SURVEY 8b "Ownership"), stream-ordered copy in either direction,

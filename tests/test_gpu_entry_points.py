@@ -195,3 +195,31 @@ def test_generate_equals_per_ply_launches(goenv):
     assert a.stats() == b.stats() and a.stats()[goenv.ST_GAMES] > B
     a.close()
     b.close()
+
+
+def test_copy_boards_branches_positions(goenv):
+    """Tree-search style branching: children = copies of a parent, each stepped with its own move."""
+    B, seed = 12, 8
+    env, oracles = midgame(goenv, B, seed, 50)
+    dev = env.device
+    parent = 3
+    kids = [6, 7, 8, 9]
+    env.copy_boards(torch.tensor([parent] * 4, dtype=torch.int32, device=dev),
+                    torch.tensor(kids, dtype=torch.int32, device=dev))
+    moves = [int(m) for m in np.flatnonzero(oracles[parent].legal())[:3]] + [-1]
+    status = torch.zeros(4, dtype=torch.int32, device=dev)
+    feat = torch.zeros(4, 25, 19, 19, device=dev)
+    env.ply_sel(idx=torch.tensor(kids, dtype=torch.int32, device=dev),
+                actions=torch.tensor(moves, dtype=torch.int64, device=dev), feat_out=feat, status_out=status)
+    assert status.cpu().tolist() == [1, 1, 1, 1]
+    for k, mv in zip(kids, moves):
+        oracles[k] = oracles[parent].clone()
+        assert oracles[k].forward(mv)[0]
+    st = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+    for b, o in enumerate(oracles):                      # parent and bystanders untouched
+        assert_canon_equal({k: v[b] for k, v in st.items()}, o.canonical(), "board %d" % b)
+    for r, k in enumerate(kids):
+        assert_planes_equal(feat[r].cpu().numpy(), oracles[k].extract(0), "child %d" % k)
+    with pytest.raises(goenv.GoEnvError):
+        env.copy_boards(torch.zeros(B + 1, dtype=torch.int32, device=dev), torch.zeros(B + 1, dtype=torch.int32, device=dev))
+    env.close()
