@@ -141,11 +141,15 @@ __device__ __forceinline__ int ply_body(BoardLds<NW>& L, const Geo<NW>& g, uint3
     }
     if (a == -4) return a;
   }
+#ifdef GOENV_ABLATE_RULES
+  advance(s, a, s.next);
+#else
   if (a < 0) {
     advance(s, a, s.next);  // pass / resign: Play's early return, go/board.cc:1092-1095
   } else {
     apply_move(L, g, lab, lastp, s, a, s.next);
   }
+#endif
   STAMP(3);
   if (MASKS) move_masks(L, g, lab, s, s.next, o);
   s.done = game_end(s) ? 1 : ((P.max_ply > 0 && s.ply > P.max_ply) ? 2 : 0);
@@ -167,6 +171,9 @@ __global__ __launch_bounds__(64 * NW) void k_ply(PlyParams P) {
     return;
   }
   STAMP(0);
+#ifdef GOENV_ABLATE_ALL
+  return;
+#endif
   BoardRec* rec = P.state + board;
   Scalars s;
   uint32_t lab[K], lastp[K];
@@ -216,7 +223,11 @@ __global__ __launch_bounds__(64 * NW) void k_ply(PlyParams P) {
     const int ply_of_sample = s.ply;
     if (P.flags & GOENV_F_COLLECT) emit_sample_meta(P.meta, b, board, g.tid, s, aug);
     (void)ply_of_sample;
+#ifdef GOENV_ABLATE_FEAT
+    if (false) {
+#else
     if (P.feat) {
+#endif
       float* out = P.feat + (size_t)b * GOENV_FEAT_FLOATS;
       switch (P.zero_first & 3) {
         case 0: write_features<NW, true, false>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
@@ -226,17 +237,23 @@ __global__ __launch_bounds__(64 * NW) void k_ply(PlyParams P) {
       }
     }
     STAMP(5);
+#ifndef GOENV_ABLATE_MASKS
     if (a != -4 && !fresh) move_masks(L, g, lab, s, s.next, o);
+#endif
     STAMP(6);
+#ifndef GOENV_ABLATE_RECSTORE
     if (a != -4 || (P.flags & (GOENV_F_RESET_ILLEGAL | GOENV_F_COLLECT)))
       store_board(rec, g, lab, lastp, o, s);
+#endif
   }
   if (g.tid == 0) {
     if (P.actions_out) P.actions_out[b] = a;
     if (P.status) P.status[b] = status;
   }
   if (skip) return;
+#ifndef GOENV_ABLATE_LEGAL
   if (P.legal) write_legal(g, o, P.legal + (size_t)b * NPTS);
+#endif
   STAMP(7);
 }
 
@@ -911,6 +928,16 @@ int goenv_ply(goenv_ctx* c, uint32_t flags, const int64_t* actions, const int32_
   if (!c) return fail("goenv_ply: ctx is NULL");
   return goenv_ply_sel(c, nullptr, 0, c->n, flags & ~GOENV_F_COLLECT, actions, aug_codes, feat_out, legal_out,
                        nullptr, actions_out, status_out, stream);
+}
+
+int goenv_ply_repeat(goenv_ctx* c, int n_steps, uint32_t flags, const int64_t* actions, const int32_t* aug_codes,
+                     float* feat_out, uint8_t* legal_out, int32_t* actions_out, int32_t* status_out, void* stream) {
+  if (n_steps < 0) return fail("goenv_ply_repeat: n_steps is negative");
+  for (int i = 0; i < n_steps; ++i) {
+    const int rc = goenv_ply(c, flags, actions, aug_codes, feat_out, legal_out, actions_out, status_out, stream);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 #ifdef GOENV_STAMPS

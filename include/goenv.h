@@ -207,6 +207,14 @@ int goenv_ply(goenv_ctx* ctx, uint32_t flags, const int64_t* actions, const int3
               float* feat_out, uint8_t* legal_out, int32_t* actions_out, int32_t* status_out,
               void* stream);
 
+/* goenv_ply_repeat: n_steps successive goenv_ply launches enqueued from native code (the same
+ * arguments every time: meant for the on-device policy, where each ply reads the state the
+ * previous one wrote).  Saves the per-call cost of a scripting-language binding when a caller
+ * steps many plies without looking at the outputs in between. */
+int goenv_ply_repeat(goenv_ctx* ctx, int n_steps, uint32_t flags, const int64_t* actions,
+                     const int32_t* aug_codes, float* feat_out, uint8_t* legal_out, int32_t* actions_out,
+                     int32_t* status_out, void* stream);
+
 /* Selections.  The three calls below act on `count` boards: board of row b is
  * idx[b] (device int32) when idx != NULL, else first + b.  Every batch array is
  * indexed by the ROW b, so a collector's batch tensors can be filled from any
