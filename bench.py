@@ -98,8 +98,10 @@ def main():
     legal = env.new(torch.uint8, 361)
     flags = goenv.F_RANDOM_POLICY | goenv.F_AUTO_RESTART
 
-    def step():
-        env.ply(flags, feat_out=feat, legal_out=legal)
+    def steps(k):
+        # k launches of the fused ply, enqueued back to back from native code (goenv_ply_repeat):
+        # the timed region then holds GPU work only, whatever the speed of the Python host
+        env.ply_repeat(k, flags, feat_out=feat, legal_out=legal)
 
     def sync():
         torch.cuda.synchronize()
@@ -107,13 +109,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    steps(args.warmup)
     sync()
     env.timer_begin()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    steps(args.steps)
     env.timer_end()
     torch.cuda.synchronize()
     kernel_ms = env.timer_ms() / args.steps          # HIP events on the launch stream
@@ -171,12 +171,10 @@ def extra_measurements(goenv, seed):
         feat, legal = env.new(torch.float32, 25, 19, 19), env.new(torch.uint8, 361)
         flags = goenv.F_RANDOM_POLICY | goenv.F_AUTO_RESTART
         steps = 300 if B == 8192 else 60
-        for _ in range(100 if B == 8192 else 150):   # into the middle game
-            env.ply(flags, feat_out=feat, legal_out=legal)
+        env.ply_repeat(100 if B == 8192 else 150, flags, feat_out=feat, legal_out=legal)   # into the middle game
         torch.cuda.synchronize()
         env.timer_begin()
-        for _ in range(steps):
-            env.ply(flags, feat_out=feat, legal_out=legal)
+        env.ply_repeat(steps, flags, feat_out=feat, legal_out=legal)
         env.timer_end()
         ms = env.timer_ms() / steps
         r = {"ply_ms": ms, "moves_per_s": B / (ms * 1e-3),
