@@ -45,18 +45,48 @@ __global__ __launch_bounds__(64) void p3_flat_aligned(float* out, int n) {
   f4 val = {1.f, 2.f, 3.f, 4.f};
   for (size_t i = a + 4 * lane; i < z; i += 256) *(f4*)(out + i) = val;
 }
+// p2 with the non-temporal (streaming) hint on every 16-byte store
+__device__ __forceinline__ void st_nt(float* p, f4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+}
+__global__ __launch_bounds__(64) void p4_planemajor_x4_nt(float* out, int n) {
+  int b = blockIdx.x, lane = threadIdx.x;
+  float* o = out + (size_t)b * FB;
+#pragma unroll
+  for (int pl = 0; pl < 25; ++pl) {
+    float v = (float)pl;
+    f4 val = {v, v + 1, v + 2, v + 3};
+    st_nt(o + pl * NP + 4 * lane, val);
+    if (lane < 26) st_nt(o + pl * NP + 256 + 4 * lane, val);
+    if (lane == 26) o[pl * NP + 360] = v;
+  }
+}
+// p2 launched as 3 waves per board (each wave a third of the planes), like the product kernel
+__global__ __launch_bounds__(192) void p5_three_waves(float* out, int n) {
+  int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* o = out + (size_t)b * FB;
+  for (int pl = w; pl < 25; pl += 3) {
+    float v = (float)pl;
+    uf4 val = {v, v + 1, v + 2, v + 3};
+    *(uf4*)(o + pl * NP + 4 * lane) = val;
+    if (lane < 26) *(uf4*)(o + pl * NP + 256 + 4 * lane) = val;
+    if (lane == 26) o[pl * NP + 360] = v;
+  }
+}
 int main(int argc, char** argv) {
   int n = argc > 1 ? atoi(argv[1]) : 65536, reps = argc > 2 ? atoi(argv[2]) : 20;
   float* out; hipMalloc(&out, (size_t)n * FB * 4 + 64);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  void (*ks[4])(float*, int) = {p0_kmajor, p1_planemajor, p2_planemajor_x4, p3_flat_aligned};
-  const char* nm[4] = {"p0 k-major dword", "p1 plane-major dword", "p2 plane-major x4 (4B aligned)", "p3 flat aligned x4"};
+  void (*ks[6])(float*, int) = {p0_kmajor, p1_planemajor, p2_planemajor_x4, p3_flat_aligned, p4_planemajor_x4_nt, p5_three_waves};
+  const char* nm[6] = {"p0 k-major dword", "p1 plane-major dword", "p2 plane-major x4 (4B aligned)", "p3 flat aligned x4",
+                       "p4 plane-major x4 nt", "p5 plane-major x4, 3 waves/board"};
+  const int bs[6] = {64, 64, 64, 64, 64, 192};
   for (int round = 0; round < 2; ++round)
-    for (int v = 0; v < 4; ++v) {
-      hipLaunchKernelGGL(ks[v], dim3(n), dim3(64), 0, 0, out, n);
+    for (int v = 0; v < 6; ++v) {
+      hipLaunchKernelGGL(ks[v], dim3(n), dim3(bs[v]), 0, 0, out, n);
       hipDeviceSynchronize();
       hipEventRecord(e0);
-      for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(ks[v], dim3(n), dim3(64), 0, 0, out, n);
+      for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(ks[v], dim3(n), dim3(bs[v]), 0, 0, out, n);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
       if (round) printf("n=%d %-34s %8.3f us  %7.1f GB/s\n", n, nm[v], ms * 1e3, (double)n * FB * 4 / (ms * 1e-3) / 1e9);
