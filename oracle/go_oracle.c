@@ -296,6 +296,155 @@ void goor_canonical(const GoBoard* b, uint8_t* color, int16_t* libs, int16_t* st
   }
 }
 
+/* ---- heuristic move filters, by copying the board and trying the move -------- */
+
+/* IsSelfAtari(board, NULL, c, player, &n), go/board.cc:168-200: legal, and the group the stone
+ * ends up in has exactly one liberty after the move (its early-outs are consequences of that). */
+static int self_atari_at(const GoBoard* b, int p, int* num_stones) {
+  GoBoard t = *b;
+  if (!play_as(&t, p, b->next, NULL)) return 0;
+  Groups g;
+  analyze(&t, &g);
+  if (g.glib[g.gid[p]] != 1) return 0;
+  *num_stones = g.gstones[g.gid[p]];
+  return 1;
+}
+
+/* IsMoveGivingSimpleKo, go/board.cc:320-335 */
+static int gives_ko_at(const GoBoard* b, const Groups* g, int p, int player) {
+  int nb[4], n = nbrs(p, nb), hits = 0;
+  for (int i = 0; i < n; ++i) {
+    int q = nb[i];
+    if (b->color[q] == S_EMPTY) return 0;
+    if (b->color[q] == player) return 0;
+    if (g->glib[g->gid[q]] == 1 && g->gstones[g->gid[q]] == 1) ++hits;
+  }
+  return hits == 1;
+}
+
+static int empty_nbrs(const GoBoard* b, int p, int out[4]) {
+  int nb[4], n = nbrs(p, nb), k = 0;
+  for (int i = 0; i < n; ++i) if (b->color[nb[i]] == S_EMPTY) out[k++] = nb[i];
+  return k;
+}
+
+#define MAX_LADDER_SEARCH 1024
+/* CheckLadderUseSearch, go/board.cc:203-317 */
+static int ladder_search(GoBoard* b, int victim, int* num_call, int depth) {
+  ++*num_call;
+  const int c = b->last[0], c2 = b->last[1];
+  Groups g;
+  analyze(b, &g);
+  const int lib = g.glib[g.gid[c]];
+  if (victim == OPP(b->next)) { /* capturer to play */
+    if (lib == 1) return depth;
+    if (lib >= 3) return 0;
+    int esc[4], n_esc = empty_nbrs(b, c, esc);
+    if (n_esc <= 1) return 0;
+    int must_block = -1;
+    for (int i = 0; i < 2; ++i) {
+      int tmp[4];
+      if (empty_nbrs(b, esc[i], tmp) == 3) { must_block = esc[i]; break; }
+    }
+    if (must_block < 0 && *num_call >= MAX_LADDER_SEARCH) must_block = esc[0];
+    if (must_block >= 0) {
+      if (play_as(b, must_block, b->next, NULL)) {
+        int d = ladder_search(b, victim, num_call, depth + 1);
+        if (d > 0) return d;
+      }
+    } else {
+      GoBoard t = *b;
+      if (play_as(&t, esc[0], t.next, NULL)) {
+        int d = ladder_search(&t, victim, num_call, depth + 1);
+        if (d > 0) return d;
+      }
+      if (play_as(b, esc[1], b->next, NULL)) {
+        int d = ladder_search(b, victim, num_call, depth + 1);
+        if (d > 0) return d;
+      }
+    }
+  } else { /* victim to play */
+    if (lib == 1) return 0;
+    int esc[4];
+    if (c2 < 0 || empty_nbrs(b, c2, esc) == 0) return 0; /* the reference calls error() here */
+    const int flee = esc[0];
+    if (play_as(b, flee, b->next, NULL)) {
+      analyze(b, &g);
+      const int l = g.glib[g.gid[flee]];
+      if (l >= 3) return 0;
+      if (l == 2) {
+        int nb[4], n = nbrs(flee, nb);
+        for (int i = 0; i < n; ++i)
+          if (b->color[nb[i]] == OPP(victim) && g.glib[g.gid[nb[i]]] == 1) return 0;
+      }
+      int d = ladder_search(b, victim, num_call, depth + 1);
+      if (d > 0) return d;
+    }
+  }
+  return 0;
+}
+
+/* CheckLadder, go/board.cc:348-391, of a legal move p of the side to move */
+static int check_ladder_at(const GoBoard* b, const Groups* g, int p, int player) {
+  int nb[4], n = nbrs(p, nb), lib = 0;
+  int seen[4], n_seen = 0, n_enemy = 0, n_self = 0, enemy_three = 0, in_atari = 0;
+  for (int i = 0; i < n; ++i) {
+    int q = nb[i];
+    if (b->color[q] == S_EMPTY) { ++lib; continue; }
+    int id = g->gid[q], dup = 0;
+    for (int j = 0; j < n_seen; ++j) dup |= seen[j] == id;
+    if (dup) continue;
+    seen[n_seen++] = id;
+    if (b->color[q] == OPP(player)) {
+      if (n_enemy >= 1) enemy_three = 0;
+      else if (g->glib[id] >= 3) enemy_three = 1;
+      ++n_enemy;
+    } else {
+      if (n_self >= 1) in_atari = 0;
+      else if (g->glib[id] == 1) in_atari = 1;
+      ++n_self;
+    }
+  }
+  if (lib != 2 || !enemy_three || !in_atari) return 0;
+  GoBoard t = *b;
+  play_as(&t, p, player, NULL);
+  int num_call = 0;
+  return ladder_search(&t, player, &num_call, 1);
+}
+
+/* same contract as goref_tactics (oracle/ref_harness.cc) */
+void goor_tactics(const GoBoard* b, int thres, int16_t* self_atari, uint8_t* gives_ko, uint8_t* cand,
+                  int16_t* libs, int16_t* ladder) {
+  Groups g;
+  analyze(b, &g);
+  const int player = b->next;
+  for (int p = 0; p < NP; ++p) {
+    self_atari[p] = 0; gives_ko[p] = 0; cand[p] = 0; ladder[p] = 0;
+    libs[2 * p] = libs[2 * p + 1] = -1;
+    if (b->color[p] != S_EMPTY) {
+      const int id = g.gid[p];
+      if (g.glib[id] <= 2) { /* find_only_liberty / find_two_liberties, board.cc:1042-1081 */
+        int k = 0;
+        for (int q = 0; q < NP && k < 2; ++q) {
+          if (b->color[q] != S_EMPTY) continue;
+          int nb[4], n = nbrs(q, nb), adj = 0;
+          for (int i = 0; i < n; ++i) adj |= b->color[nb[i]] != S_EMPTY && g.gid[nb[i]] == id;
+          if (adj) libs[2 * p + k++] = (int16_t)q;
+        }
+      }
+      continue;
+    }
+    if (!legal_at(b, &g, p, player)) continue;
+    int n = 0;
+    const int sa = self_atari_at(b, p, &n);
+    if (sa) self_atari[p] = (int16_t)n;
+    gives_ko[p] = (uint8_t)gives_ko_at(b, &g, p, player);
+    ladder[p] = (int16_t)check_ladder_at(b, &g, p, player);
+    /* FindAllCandidateMoves, board.cc:685-715 */
+    cand[p] = (uint8_t)(!true_eye(b, p, player) && !(sa && n >= thres));
+  }
+}
+
 /* stage an arbitrary position (same contract as goenv_set_state) */
 void goor_set_state(GoBoard* b, const uint8_t* color, const uint16_t* last_placed, const int32_t* sc) {
   memcpy(b->color, color, NP);

@@ -47,6 +47,7 @@ def _load(path, prefix):
     api["extract"] = f("extract", None, C.c_void_p, C.c_int, _f32p)
     api["tt_score"] = f("tt_score", C.c_float, C.c_void_p)
     api["fast_score"] = f("fast_score", C.c_float, C.c_void_p, C.c_int)
+    api["tactics"] = f("tactics", None, C.c_void_p, C.c_int, _i16p, _u8p, _u8p, _i16p, _i16p)
     api["policy_move"] = f("policy_move", C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64)
     api["bench_playouts"] = f("bench_playouts", C.c_int64, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
                               C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double))
@@ -138,6 +139,16 @@ class _Board:
 
     def fast_score(self, rule=0):
         return float(self.api()["fast_score"](self.ptr, rule))
+
+    def tactics(self, thres=1):
+        """Heuristic move filters for the side to move: dict of per-point arrays."""
+        sa = np.zeros(NP_, np.int16)
+        ko = np.zeros(NP_, np.uint8)
+        cand = np.zeros(NP_, np.uint8)
+        libs = np.zeros((NP_, 2), np.int16)
+        ladder = np.zeros(NP_, np.int16)
+        self.api()["tactics"](self.ptr, int(thres), sa, ko, cand, libs.reshape(-1), ladder)
+        return dict(self_atari=sa, gives_ko=ko, cand=cand, libs=libs, ladder=ladder)
 
     def policy_move(self, seed, board_id, game=0):
         return int(self.api()["policy_move"](self.ptr, seed, board_id, game))

@@ -174,6 +174,51 @@ int goref_action2coord(int aug_code, int action) {
 float goref_tt_score(const void* b) { return GetTrompTaylorScore((const Board*)b, NULL, NULL); }
 float goref_fast_score(const void* b, int rule) { return GetFastScore((const Board*)b, rule); }
 
+// Heuristic move filters of go/board.cc for the side to move, one value per point in export
+// order.  All five come straight from the reference's functions:
+//   self_atari[p] = num_stones of IsSelfAtari(board, NULL, c, player, &n) (:168-200), 0 if not
+//   gives_ko[p]   = IsMoveGivingSimpleKo (:320-335) of a legal move (ids from TryPlay2)
+//   cand[p]       = FindAllCandidateMoves(board, player, thres) (:685-715)
+//   libs[p][2]    = find_only_liberty (:1042-1058) / find_two_liberties (:1060-1081) of the group
+//                   of the stone at p, sorted ascending (the reference's order follows its stone
+//                   list), -1 = none
+//   ladder[p]     = CheckLadder (:348-391) of a legal move
+void goref_tactics(const void* b, int thres, int16_t* self_atari, uint8_t* gives_ko, uint8_t* cand,
+                   int16_t* libs, int16_t* ladder) {
+  const Board* board = (const Board*)b;
+  const Stone player = board->_next_player;
+  memset(cand, 0, NUM_INTERSECTION);
+  AllMoves am;
+  FindAllCandidateMoves(board, player, thres, &am);
+  for (int i = 0; i < am.num_moves; ++i) cand[EXPORT_OFFSET(am.moves[i])] = 1;
+  for (int x = 0; x < BOARD_SIZE; ++x) {
+    for (int y = 0; y < BOARD_SIZE; ++y) {
+      const Coord c = OFFSETXY(x, y);
+      const int p = EXPORT_OFFSET_XY(x, y);
+      self_atari[p] = 0; gives_ko[p] = 0; ladder[p] = 0;
+      libs[2 * p] = libs[2 * p + 1] = -1;
+      if (HAS_STONE(board->_infos[c].color)) {
+        const short id = board->_infos[c].id;
+        Coord m[2];
+        if (board->_groups[id].liberties == 1 && find_only_liberty(board, id, &m[0])) {
+          libs[2 * p] = (int16_t)EXPORT_OFFSET(m[0]);
+        } else if (board->_groups[id].liberties == 2 && find_two_liberties(board, id, m)) {
+          int a0 = EXPORT_OFFSET(m[0]), a1 = EXPORT_OFFSET(m[1]);
+          libs[2 * p] = (int16_t)(a0 < a1 ? a0 : a1);
+          libs[2 * p + 1] = (int16_t)(a0 < a1 ? a1 : a0);
+        }
+        continue;
+      }
+      GroupId4 ids;
+      if (!TryPlay2(board, c, &ids)) continue;
+      int n = 0;
+      if (IsSelfAtari(board, NULL, c, player, &n)) self_atari[p] = (int16_t)n;
+      gives_ko[p] = IsMoveGivingSimpleKo(board, &ids, player) ? 1 : 0;
+      ladder[p] = (int16_t)CheckLadder(board, &ids, player);
+    }
+  }
+}
+
 // One ply of the cfg-2 policy on the reference board.  Returns the action played.
 int goref_policy_move(const void* b, uint64_t seed, uint64_t board_id, uint64_t game) {
   const Board* board = (const Board*)b;

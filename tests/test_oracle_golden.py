@@ -110,3 +110,37 @@ def test_empty_board_and_set_state_roundtrip():
     b2 = OracleBoard()
     b2.set_state(c["color"], c["last_placed"], c["scalars"])
     assert board_digest(b2) == board_digest(b)
+
+
+def test_move_filters_golden():
+    """Heuristic move filters against vectors recorded from the reference build
+    (tests/golden/make_golden_tactics.py)."""
+    gold = load_golden("tactics.json")
+    boards = {}
+    n_ladder = 0
+    for pos in gold["positions"]:
+        rec = gold["records"][pos["record"]]
+        key = pos["record"]
+        if key not in boards:
+            b = OracleBoard()
+            b.apply_handicap(rec["handi"])
+            boards[key] = [b, 0]
+        b, done = boards[key]
+        for m in rec["moves"][done:pos["n_moves"]]:
+            assert b.forward(m)[0]
+        boards[key][1] = pos["n_moves"]
+        t = b.tactics(pos["thres"])
+
+        def dense(sp, shape, dtype):
+            a = np.zeros(shape, dtype)
+            for i, v in sp:
+                a[i] = v
+            return a
+        where = "%s after %d moves" % (key, pos["n_moves"])
+        assert np.array_equal(t["self_atari"], dense(pos["self_atari"], 361, np.int16)), where
+        assert np.array_equal(t["gives_ko"], dense(pos["gives_ko"], 361, np.uint8)), where
+        assert np.array_equal(1 - t["cand"], dense(pos["not_cand"], 361, np.uint8)), where
+        assert np.array_equal(t["libs"] + 1, dense(pos["libs_plus1"], (361, 2), np.int16)), where
+        assert np.array_equal(t["ladder"], dense(pos["ladder"], 361, np.int16)), where
+        n_ladder += len(pos["ladder"])
+    assert n_ladder >= 20

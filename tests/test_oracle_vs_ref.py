@@ -54,3 +54,48 @@ def test_policy_and_d4_agree():
         for a in range(361):
             assert RefBoard.aug_action(code, a) == OracleBoard.aug_action(code, a)
             assert RefBoard.aug_action_inv(code, a) == OracleBoard.aug_action_inv(code, a)
+
+
+def _tactics_equal(r, o, thres, where):
+    a, b = r.tactics(thres), o.tactics(thres)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), (where, k)
+    return a
+
+
+def test_move_filters_on_game_records_and_playouts():
+    """IsSelfAtari / IsMoveGivingSimpleKo / FindAllCandidateMoves / find_*_libert* / CheckLadder
+    (SURVEY 8f-3): the restatement against the reference on every second position of the corpus
+    records (real games: ladders up to depth 45) and on random playouts."""
+    import glob
+    import os
+    corpus = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "corpus")
+    hits = dict(sa=0, ko=0, ladder=0)
+    for f in sorted(glob.glob(os.path.join(corpus, "*.sgf"))):
+        rec = RefBoard.sgf_load(f)
+        r, o = RefBoard(), OracleBoard()
+        r.apply_handicap(rec["handi"])
+        o.apply_handicap(rec["handi"])
+        for i, m in enumerate(rec["moves"]):
+            ok, _ = r.forward(int(m))
+            o.forward(int(m))
+            if not ok:
+                break
+            if i % 2 == 0:
+                a = _tactics_equal(r, o, [1, 3, 100][i % 3], (f, i))
+                hits["sa"] += int((a["self_atari"] > 0).sum())
+                hits["ko"] += int(a["gives_ko"].sum())
+                hits["ladder"] += int((a["ladder"] > 0).sum())
+    assert hits["sa"] > 1000 and hits["ko"] > 50 and hits["ladder"] > 50, hits
+    rng = np.random.default_rng(5)
+    for g in range(4):
+        r, o = RefBoard(), OracleBoard()
+        for ply in range(500):
+            idx = np.flatnonzero(r.candidates())
+            a = -1 if len(idx) == 0 else int(rng.choice(idx))
+            _, end = r.forward(a)
+            o.forward(a)
+            if ply % 4 == 0:
+                _tactics_equal(r, o, [1, 2, 5][ply % 3], ("playout", g, ply))
+            if end:
+                break
