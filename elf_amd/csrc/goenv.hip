@@ -14,6 +14,7 @@
 
 #include "../../include/goenv.h"
 #include "goenv_device.h"
+#include "goenv_tactics.h"
 
 using namespace goenv;
 
@@ -684,6 +685,28 @@ __global__ __launch_bounds__(128) void k_copy_boards(BoardRec* state, int n_tota
   for (int i = threadIdx.x; i < (int)(sizeof(BoardRec) / 16); i += blockDim.x) out[i] = in[i];
 }
 
+// Heuristic move filters (goenv_tactics.h): always one wavefront per board -- the work is either
+// per point (one pass) or a played-out line (serial), neither gains from more waves.
+__global__ __launch_bounds__(64) void k_tactics(const BoardRec* state, int n_total, const int32_t* idx, int first,
+                                                int count, int thres, TacticsOut out) {
+  __shared__ BoardLds<1> L;
+  __shared__ TacticsLds X;
+  const int b = blockIdx.x;
+  if (b >= count) return;
+  const int board = board_of(idx, first, n_total, b);
+  if (board < 0) return;
+  Geo<1> g;
+  geo_init(g);
+  constexpr int K = Geo<1>::K;
+  Scalars s;
+  uint32_t lab[K], lastp[K];
+  Masks m;
+  Own<1> o;
+  load_record(state + board, L, g, lab, lastp, s, m);
+  own_from_masks(g, m, o);
+  tactics(L, X, g, lab, s, o, thres, out, (size_t)b);
+}
+
 // Launch of a kernel template on the waves-per-board count chosen for this call.
 #define GO_LAUNCH(NWSEL, KERNEL, GRID, STREAM, ...)                                                  \
   do {                                                                                               \
@@ -1038,6 +1061,21 @@ int goenv_replay(goenv_ctx* c, const int32_t* idx, int first, int count, const i
   P.n = count; P.idx = idx; P.first = first;
   P.max_ply = 0;  // a replayed record is not subject to the playout ply cap
   GO_LAUNCH(pick_nw(c, count), k_replay, count, S(stream), P, moves, stride, nmoves, napplied_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int goenv_tactics(goenv_ctx* c, const int32_t* idx, int first, int count, int self_atari_thres,
+                  const goenv_tactics_out* out, void* stream) {
+  if (check_sel(c, idx, first, count, "goenv_tactics")) return -1;
+  if (!out) return fail("goenv_tactics: out is NULL");
+  if (self_atari_thres < 0) return fail("goenv_tactics: self_atari_thres must be >= 0");
+  if (count == 0) return 0;
+  TacticsOut t;
+  t.self_atari = out->self_atari; t.gives_ko = out->gives_ko; t.cand = out->cand; t.libs = out->libs;
+  t.ladder = out->ladder;
+  hipLaunchKernelGGL(k_tactics, dim3(count), dim3(64), 0, S(stream), c->state, c->n, idx, first, count,
+                     self_atari_thres, t);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -69,6 +69,7 @@ _SIGS = {
     "goenv_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goenv_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goenv_fast_score": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "goenv_tactics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "goenv_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
     "goenv_stats_ptr": (C.c_void_p, [C.c_void_p]),
     "goenv_stats_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
@@ -124,6 +125,12 @@ class SampleOut(C.Structure):
                 raise GoEnvError("sample field %s must be a contiguous %s tensor" % (k, cls.DTYPES[k]))
             setattr(o, k, t.data_ptr())
         return o
+
+
+class TacticsOut(C.Structure):
+    """goenv_tactics_out: device arrays (or NULL) of the heuristic move filters."""
+    _fields_ = [(k, C.c_void_p) for k in ("self_atari", "gives_ko", "cand", "libs", "ladder")]
+    DTYPES = dict(self_atari=torch.int16, gives_ko=torch.uint8, cand=torch.uint8, libs=torch.int16, ladder=torch.int16)
 
 
 def _ptr(t):
@@ -317,6 +324,23 @@ class GoEnv:
     def fast_score(self, rule, out):
         self._check(out, torch.float32, (self.n,), "out")
         self._chk(self.lib.goenv_fast_score(self._h, int(rule), _ptr(out), self._stream()))
+
+    def tactics(self, self_atari_thres=1, idx=None, first=0, count=None, **outs):
+        """goenv_tactics: outs = self_atari / gives_ko / cand / libs / ladder tensors ([count, 361],
+        libs [count, 361, 2]); returns the dict passed in."""
+        if idx is not None:
+            count = idx.numel()
+            self._check(idx, torch.int32, (count,), "idx")
+        elif count is None:
+            count = self.n - first
+        o = TacticsOut()
+        for k, t in outs.items():
+            shape = (count, NUM_POINTS, 2) if k == "libs" else (count, NUM_POINTS)
+            self._check(t, TacticsOut.DTYPES[k], shape, k)
+            setattr(o, k, t.data_ptr())
+        self._chk(self.lib.goenv_tactics(self._h, _ptr(idx), first, count, int(self_atari_thres), C.byref(o),
+                                         self._stream()))
+        return outs
 
     def finish(self):
         self._chk(self.lib.goenv_finish(self._h, self._stream()))

@@ -304,6 +304,36 @@ int goenv_score(goenv_ctx* ctx, float* score_out, float* fast_out, void* stream)
  * rule 0 = RULE_CHINESE, 1 = RULE_JAPANESE. */
 int goenv_fast_score(goenv_ctx* ctx, int rule, float* out, void* stream);
 
+/* goenv_tactics: the heuristic move filters of go/board.cc for the side to move of the selected
+ * boards (idx / first / count as in goenv_collect_sel), one value per point in export order
+ * p = x*19+y; row r of every output belongs to the r-th selected board; any pointer may be NULL.
+ *   self_atari int16 [count][361]    IsSelfAtari(board, NULL, c, next, &n) (go/board.cc:168-200):
+ *                                    n = stones of the group left with one liberty, 0 = not a
+ *                                    self-atari (or not a legal move)
+ *   gives_ko   u8    [count][361]    IsMoveGivingSimpleKo (go/board.cc:320-335) of a legal move
+ *   cand       u8    [count][361]    FindAllCandidateMoves(board, next, self_atari_thres)
+ *                                    (go/board.cc:685-715): legal, not an own true eye, not a
+ *                                    self-atari of >= self_atari_thres stones
+ *   libs       int16 [count][361][2] the liberties of the group of the stone at p when it has one
+ *                                    (find_only_liberty, go/board.cc:1042-1058: {m, -1}) or two
+ *                                    (find_two_liberties, :1060-1081: ascending; the reference's
+ *                                    order follows its stone list), else {-1, -1}
+ *   ladder     int16 [count][361]    CheckLadder (go/board.cc:348-391, search :203-317) of a legal
+ *                                    move: depth of the ladder it runs into, 0 = none; -1 = the
+ *                                    search had more than 16 two-way branches pending at once and
+ *                                    was abandoned (the reference recurses without that bound; on
+ *                                    game records the maximum seen is 4)
+ * Boards are not modified. */
+typedef struct goenv_tactics_out {
+  int16_t* self_atari;
+  uint8_t* gives_ko;
+  uint8_t* cand;
+  int16_t* libs;
+  int16_t* ladder;
+} goenv_tactics_out;
+int goenv_tactics(goenv_ctx* ctx, const int32_t* idx, int first, int count, int self_atari_thres,
+                  const goenv_tactics_out* out, void* stream);
+
 /* Statistics ---------------------------------------------------------------
  * goenv_finish: score every finished board that has not been counted yet and
  * add it to the device stats vector (boards keep their state).
