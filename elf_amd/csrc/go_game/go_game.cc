@@ -30,6 +30,7 @@
 #include "device_env.h"
 #include "offline_loader.h"
 #include "sgf_record.h"
+#include "tree_search.h"
 
 namespace py = pybind11;
 using namespace gogame;
@@ -37,21 +38,6 @@ using namespace gogame;
 // ------------------------------------------------------------------------------------------
 // option / descriptor PODs (field names as in the reference)
 // ------------------------------------------------------------------------------------------
-
-// elf/tree_search_options.h:21-55.  Carried for interface compatibility; tree search itself is
-// out of scope of this build.
-struct TSOptions {
-  int max_num_moves = 0;
-  int num_threads = 16;
-  int num_rollout_per_thread = 100;
-  bool verbose = false;
-  bool verbose_time = false;
-  std::string save_tree_filename;
-  bool persistent_tree = false;
-  std::string pick_method = "most_visited";
-  bool use_prior = false;
-  int pseudo_games = 0;
-};
 
 // elf/python_options_utils_cpp.h:20-55
 struct ContextOptions {
@@ -199,8 +185,16 @@ class GameContext {
   GameContext(const ContextOptions& co, const GameOptions& opt) : co_(co), opt_(opt) {
     if (co_.num_games <= 0) throw std::range_error("ContextOptions.num_games must be positive");
     offline_ = !(opt_.mode == "online" || opt_.mode == "selfplay");
-    if (opt_.use_mcts)
-      throw std::range_error("use_mcts: tree search is outside this build (SURVEY 8f); run the policy directly");
+    mcts_ = opt_.use_mcts && !offline_;  // GoGame::Init builds an MCTSGoAI only for online / selfplay, go/game.cc:38-41
+    if (mcts_) {
+      const TSOptions& ts = co_.mcts_options;
+      if (ts.persistent_tree) throw std::range_error("mcts_options.persistent_tree is not supported: every move starts a fresh tree");
+      if (ts.num_threads < 1 || ts.num_rollout_per_thread < 1)
+        throw std::range_error("mcts_options: num_threads and num_rollout_per_thread must be >= 1");
+      if (ts.pick_method != "most_visited" && ts.pick_method != "strongest_prior" && ts.pick_method != "uniform_random")
+        throw std::range_error("MCTS Pick method unknown! " + ts.pick_method);
+      tick_ = ts.num_threads + 1;
+    }
     if (offline_ && !opt_.list_filename.empty()) {
       if (!corpus_.load_list(opt_.list_filename))
         std::cout << "Loading " << opt_.list_filename << " failed!" << std::endl;
@@ -306,10 +300,24 @@ class GameContext {
     if (collectors_.empty()) throw std::range_error("Start(): no collectors were added");
     const int npt = offline_ ? std::max(1, opt_.num_games_per_thread) : 1;
     if (offline_ && corpus_.size() == 0) throw std::range_error("Start(): offline mode needs a readable list_filename");
-    env_.reset(new DeviceEnv(opt_.gpu, co_.num_games * npt, opt_.seed ? opt_.seed : 1, opt_.komi, opt_.ply_cap));
+    // tree search: every game owns a pool of node positions behind the games' own boards
+    const int pool = mcts_ ? co_.mcts_options.num_threads * co_.mcts_options.num_rollout_per_thread : 0;
+    const long long n_boards = (long long)co_.num_games * (mcts_ ? 1 + pool : npt);
+    if (n_boards > (1ll << 30)) throw std::range_error("Start(): num_games x node pool exceeds 2^30 boards");
+    env_.reset(new DeviceEnv(opt_.gpu, (int)n_boards, opt_.seed ? opt_.seed : 1, opt_.komi, opt_.ply_cap));
     env_->set_stream(stream_);
     games_.clear();
     games_.resize(co_.num_games);
+    searches_.clear();
+    finished_.clear();
+    pick_rng_.seed(opt_.seed ? opt_.seed : 1);
+    if (mcts_) {
+      if (group_of("actor") < 0) throw std::range_error("Start(): use_mcts needs a collector that takes \"actor\" samples");
+      for (int g = 0; g < co_.num_games; ++g) {
+        searches_.emplace_back(new TreeSearch(co_.mcts_options, co_.num_games + g * pool, pool));
+        games_[g].requests.resize(co_.mcts_options.num_threads);
+      }
+    }
     for (auto& g : groups_) g.ready.clear();
     const uint64_t base_seed = opt_.seed ? (uint64_t)opt_.seed : clock_seed();
     for (int g = 0; g < co_.num_games; ++g) {
@@ -332,6 +340,7 @@ class GameContext {
       produce_sample(g);
     }
     started_ = true;
+    finalize_searches();
   }
 
   void Stop() {
@@ -341,6 +350,8 @@ class GameContext {
     }
     for (auto& c : collectors_) { c->busy = false; c->games.clear(); }
     games_.clear();
+    searches_.clear();
+    finished_.clear();
     env_.reset();
     started_ = false;
   }
@@ -367,13 +378,14 @@ class GameContext {
     Collector& c = collector(infos.gid);
     if (!c.busy) throw std::range_error("Steps(): collector " + std::to_string(infos.gid) + " has no batch outstanding");
     if (offline_) steps_offline(c);
+    else if (leaf_batch(c)) steps_mcts(c);
     else steps_play(c);
     c.busy = false;
-    const int e = c.exclusive_id;
-    for (int g : c.games) produce_sample(g);
-    (void)e;
+    if (!leaf_batch(c))
+      for (int ticket : c.games) produce_sample(ticket / tick_);
     c.games.clear();
     c.boards.clear();
+    finalize_searches();
   }
 
   void PrintSummary() const {
@@ -386,11 +398,25 @@ class GameContext {
   // are scored first.  This is the buffer a multi-GPU job all-reduces.
   std::vector<int64_t> Stats() {
     need_env();
-    chk(goenv_finish(env_->ctx(), env_->stream()), "goenv_finish");
+    // (tree search: the node positions behind the games are not games; only restarts count)
+    if (!mcts_) chk(goenv_finish(env_->ctx(), env_->stream()), "goenv_finish");
     std::vector<int64_t> out(GOENV_NUM_STATS);
     chk(goenv_stats_host(env_->ctx(), out.data(), env_->stream()), "goenv_stats_host");
     return out;
   }
+  // tree search: what the last finished search of `game_idx` chose, and the search in progress
+  py::dict SearchInfo(int game_idx) {
+    if (!mcts_) throw std::range_error("SearchInfo: the context does not run a tree search (use_mcts)");
+    if (game_idx < 0 || game_idx >= co_.num_games || !started_) throw std::range_error("SearchInfo: no such game");
+    py::dict d;
+    d["last_move"] = games_[game_idx].last_move;
+    d["moves_played"] = games_[game_idx].moves_played;
+    d["ply"] = games_[game_idx].ply;
+    d["nodes"] = searches_[game_idx]->num_nodes();
+    d["root_edges"] = searches_[game_idx]->root_edges();
+    return d;
+  }
+
   uint64_t StatsPtr() { need_env(); return reinterpret_cast<uint64_t>(goenv_stats_ptr(env_->ctx())); }
 
   std::string ShowBoard(int game_idx) {  // go/game_context.h:89-92
@@ -434,6 +460,9 @@ class GameContext {
     PendingSample sample;
     int phase = 1;      // online mode: 0 = human to move, 1 = actor to move
     int ply = 1;        // host mirror of _ply for play modes that keep host sequencing
+    std::vector<LeafRequest> requests;  // tree search: the outstanding leaf of every search thread
+    int last_move = -3;                 // tree search: the move the last finished search played
+    long moves_played = 0;
   };
   struct Group {
     std::string name;
@@ -453,6 +482,14 @@ class GameContext {
   std::vector<Group> groups_;
   std::vector<GameSlot> games_;
   size_t rr_group_ = 0;
+  // tree search (use_mcts): a batch row is a ticket = game * tick_ + (0: the game's own sample,
+  // 1 + t: the leaf of search thread t); without tree search tick_ = 1 and tickets are game ids
+  bool mcts_ = false;
+  int tick_ = 1;
+  std::vector<std::unique_ptr<TreeSearch>> searches_;
+  std::vector<int> finished_;   // games whose search has spent its rollouts
+  std::mt19937 pick_rng_;
+  DevBuf ts_src_, ts_dst_, ts_act_, ts_status_, ts_topa_, ts_topp_, ts_v_;
 
   static uint64_t clock_seed() {
     using namespace std::chrono;
@@ -494,9 +531,71 @@ class GameContext {
       }
       gs.sample.aug = 0;  // drawn in wait_impl, at extract time, after Prepare
     }
+    if (mcts_ && gs.phase == 1) {  // MCTSAI_T::Act: a fresh tree rooted at the game's position
+      searches_[g]->begin(g);
+      pump(g);
+      return;
+    }
     const int e = group_of(sample_name(gs));
     if (e < 0) throw std::range_error("no collector takes samples named \"" + sample_name(gs) + "\"");
-    groups_[e].ready.push_back(g);
+    groups_[e].ready.push_back(g * tick_);
+  }
+
+  // lets the search threads of game g run until each waits for a leaf; queues those leaves
+  void pump(int g) {
+    std::vector<LeafRequest> rq;
+    searches_[g]->advance(&rq);
+    const int e = group_of("actor");
+    for (const LeafRequest& r : rq) {
+      games_[g].requests[r.thread] = r;
+      groups_[e].ready.push_back(g * tick_ + 1 + r.thread);
+    }
+    if (searches_[g]->done()) finished_.push_back(g);
+  }
+
+  bool leaf_batch(const Collector& c) const {
+    if (!mcts_ || c.games.empty()) return false;
+    int leaves = 0;
+    for (int ticket : c.games) leaves += ticket % tick_ != 0;
+    if (leaves != 0 && leaves != (int)c.games.size())
+      throw std::range_error("a batch mixes search leaves and game samples: give \"actor\" and \"human_actor\" their own collectors");
+    return leaves != 0;
+  }
+
+  // MCTSAI_T::Act's tail for every game whose rollouts are spent: pick the move, play it on the
+  // game's board (GoGame::Act, go/game.cc:80-93), start the next sample
+  void finalize_searches() {
+    while (!finished_.empty()) {
+      std::vector<int> games;
+      games.swap(finished_);
+      const int m = (int)games.size();
+      std::vector<int32_t> boards(games.begin(), games.end());
+      std::vector<int64_t> acts(m);
+      for (int i = 0; i < m; ++i) acts[i] = searches_[games[i]]->best_action(&pick_rng_);
+      ts_dst_.ensure(env_->ctx(), (size_t)m * 4);
+      ts_act_.ensure(env_->ctx(), (size_t)m * 8);
+      ts_status_.ensure(env_->ctx(), (size_t)m * 4);
+      env_->h2d(ts_dst_.get(), boards.data(), (size_t)m * 4);
+      env_->h2d(ts_act_.get(), acts.data(), (size_t)m * 8);
+      uint32_t flags = GOENV_F_RESET_ILLEGAL;
+      if (opt_.end_on_two_passes || opt_.ply_cap > 0) flags |= GOENV_F_RESTART_AFTER_END;
+      chk(goenv_ply_sel(env_->ctx(), ts_dst_.as<int32_t>(), 0, m, flags, ts_act_.as<int64_t>(), nullptr, nullptr,
+                        nullptr, nullptr, nullptr, ts_status_.as<int32_t>(), env_->stream()), "goenv_ply_sel");
+      std::vector<int32_t> st(m);
+      env_->d2h(st.data(), ts_status_.get(), (size_t)m * 4);
+      env_->sync();
+      const bool has_human = opt_.mode == "online" && group_of("human_actor") >= 0 &&
+                             groups_[group_of("human_actor")].name == "human_actor";
+      for (int i = 0; i < m; ++i) {
+        GameSlot& gs = games_[games[i]];
+        gs.last_move = (int)acts[i];
+        gs.moves_played += 1;
+        if (st[i] == 1) gs.ply += 1;
+        else gs.ply = 1;  // illegal / ended: the board was reset
+        if (has_human) gs.phase = 0;
+        produce_sample(games[i]);
+      }
+    }
   }
 
   Infos wait_impl(int only_gid) {
@@ -551,14 +650,26 @@ class GameContext {
     std::vector<int32_t> aug(n, 0);
     std::vector<int32_t> meta[8];
     std::vector<int64_t> off_a;
-    const bool host_meta = offline_ || opt_.mode == "online";
+    const bool host_meta = offline_ || opt_.mode == "online" || mcts_;
     if (host_meta)
       for (auto& m : meta) m.assign(n, 0);
     if (offline_) off_a.assign((size_t)n * opt_.num_future_actions, 0);
+    std::vector<int32_t> mk_src, mk_dst;   // tree search: leaf positions still to be made
+    std::vector<int64_t> mk_act;
     for (int r = 0; r < n; ++r) {
-      const int g = c.games[r];
+      const int g = c.games[r] / tick_, leaf = c.games[r] % tick_;
       GameSlot& gs = games_[g];
-      if (offline_) {
+      if (leaf) {
+        // MCTSActor::evaluate -> DirectPredictAI::Act on the leaf's state (go/mcts.h:29-34,
+        // go/go_ai.h:79-87) through the search thread's spawned AIComm (elf/mcts.h:172-178)
+        const LeafRequest& rq = gs.requests[leaf - 1];
+        c.boards[r] = rq.slot;
+        if (rq.parent_slot >= 0) { mk_src.push_back(rq.parent_slot); mk_dst.push_back(rq.slot); mk_act.push_back(rq.action); }
+        TreeSearch& ts = *searches_[g];
+        meta[0][r] = g; meta[1][r] = ts.seq_of(leaf - 1); meta[2][r] = 0; meta[3][r] = 0;
+        ts.bump_seq(leaf - 1);
+        meta[4][r] = gs.ply + rq.depth; meta[5][r] = 0; meta[6][r] = 0; meta[7][r] = -1;
+      } else if (offline_) {
         OfflineLoader& ld = *gs.loaders[gs.sample.loader];
         c.boards[r] = ld.board();
         // Prepare (elf/ai_comm.h:62-67), then extract (offpolicy_loader.cc:128-145)
@@ -581,6 +692,17 @@ class GameContext {
           meta[4][r] = gs.ply; meta[5][r] = 0; meta[6][r] = 0; meta[7][r] = -1;
         }
       }
+    }
+    if (!mk_src.empty()) {  // TSOneThreadT::_forward for every new leaf: copy of the parent, forward(a)
+      const size_t m = mk_src.size();
+      ts_src_.ensure(env_->ctx(), m * 4); ts_dst_.ensure(env_->ctx(), m * 4); ts_act_.ensure(env_->ctx(), m * 8);
+      env_->h2d(ts_src_.get(), mk_src.data(), m * 4);
+      env_->h2d(ts_dst_.get(), mk_dst.data(), m * 4);
+      env_->h2d(ts_act_.get(), mk_act.data(), m * 8);
+      chk(goenv_copy_boards(env_->ctx(), ts_src_.as<int32_t>(), ts_dst_.as<int32_t>(), (int)m, env_->stream()),
+          "goenv_copy_boards");
+      chk(goenv_ply_sel(env_->ctx(), ts_dst_.as<int32_t>(), 0, (int)m, 0u, ts_act_.as<int64_t>(), nullptr, nullptr,
+                        nullptr, nullptr, nullptr, nullptr, env_->stream()), "goenv_ply_sel");
     }
     c.contiguous = true;
     for (int r = 1; r < n; ++r)
@@ -683,7 +805,7 @@ class GameContext {
     const bool online = opt_.mode == "online";
     uint32_t flags = 0;
     int human = 0;
-    for (int g : c.games) human += games_[g].phase == 0;
+    for (int ticket : c.games) human += games_[ticket / tick_].phase == 0;
     if (!(online && human)) flags |= GOENV_F_RESET_ILLEGAL;  // a human's illegal move is asked again
     if (opt_.end_on_two_passes || opt_.ply_cap > 0) flags |= GOENV_F_RESTART_AFTER_END;
     int32_t* d_status = nullptr;
@@ -699,7 +821,7 @@ class GameContext {
       env_->sync();
       const bool has_human = group_of("human_actor") >= 0 && groups_[group_of("human_actor")].name == "human_actor";
       for (int r = 0; r < n; ++r) {
-        GameSlot& gs = games_[c.games[r]];
+        GameSlot& gs = games_[c.games[r] / tick_];
         if (gs.phase == 0) {
           if (st[r] == 1) { gs.ply += 1; gs.phase = 1; }
         } else {
@@ -709,6 +831,40 @@ class GameContext {
         }
       }
     }
+  }
+
+  // tree search: the replies (pi, V) of a batch of leaves.  DirectPredictAI::get_last_pi keeps the
+  // five legal points of largest pi (go/go_ai.h:24-68) -- chosen on the device against each leaf's
+  // legal ballots -- and the node is expanded with them (tree_search_node.h:87-111).
+  void steps_mcts(Collector& c) {
+    const int n = (int)c.games.size();
+    constexpr int K = 5;
+    const int32_t* d_idx = c.contiguous ? nullptr : c.idx.as<int32_t>();
+    const int first = c.contiguous ? c.boards[0] : 0;
+    const float* d_pi = (const float*)reply_ptr(c, "pi", c.stage_pi, (size_t)n * GOENV_NUM_POINTS * 4);
+    auto itv = c.reply.find("V");
+    if (!d_pi || itv == c.reply.end())
+      throw std::range_error("Steps(): tree search needs \"pi\" and \"V\" in the reply of collector " + std::to_string(c.gid));
+    ts_topa_.ensure(env_->ctx(), (size_t)n * K * 4);
+    ts_topp_.ensure(env_->ctx(), (size_t)n * K * 4);
+    chk(goenv_topk_policy(env_->ctx(), d_idx, first, n, d_pi, nullptr, K, ts_topa_.as<int32_t>(), ts_topp_.as<float>(),
+                          env_->stream()), "goenv_topk_policy");
+    std::vector<int32_t> top_a((size_t)n * K);
+    std::vector<float> top_p((size_t)n * K), value(n);
+    env_->d2h(top_a.data(), ts_topa_.get(), top_a.size() * 4);
+    env_->d2h(top_p.data(), ts_topp_.get(), top_p.size() * 4);
+    if (itv->second.device) env_->d2h(value.data(), itv->second.p, (size_t)n * 4);
+    env_->sync();
+    if (!itv->second.device) std::memcpy(value.data(), itv->second.p, (size_t)n * 4);
+    std::vector<int> touched;
+    for (int r = 0; r < n; ++r) {
+      const int g = c.games[r] / tick_, t = c.games[r] % tick_ - 1;
+      searches_[g]->expand(t, &top_a[(size_t)r * K], &top_p[(size_t)r * K], K, value[r]);
+      if (touched.empty() || touched.back() != g) touched.push_back(g);
+    }
+    std::sort(touched.begin(), touched.end());
+    touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+    for (int g : touched) pump(g);
   }
 
   // offline: OfflineLoader::handle_response -> next() for every sample of the batch
@@ -832,7 +988,37 @@ PYBIND11_MODULE(go_game, m) {
       .def("ShowBoard", &GameContext::ShowBoard)
       .def("SetStream", &GameContext::SetStream)
       .def("Stats", &GameContext::Stats)
-      .def("StatsPtr", &GameContext::StatsPtr);
+      .def("StatsPtr", &GameContext::StatsPtr)
+      .def("SearchInfo", &GameContext::SearchInfo);
+
+  // the host-side tree search by itself (CPU tests drive it against a board engine of their own)
+  py::class_<TreeSearch>(m, "TreeSearch")
+      .def(py::init<const TSOptions&, int, int>())
+      .def("begin", &TreeSearch::begin)
+      .def("advance", [](TreeSearch& ts) {
+        std::vector<LeafRequest> rq;
+        ts.advance(&rq);
+        py::list out;
+        for (const LeafRequest& r : rq) {
+          py::dict d;
+          d["thread"] = r.thread; d["node"] = r.node; d["slot"] = r.slot; d["parent_slot"] = r.parent_slot;
+          d["action"] = r.action; d["depth"] = r.depth;
+          out.append(d);
+        }
+        return out;
+      })
+      .def("expand", [](TreeSearch& ts, int thread, const std::vector<int32_t>& actions, const std::vector<float>& priors,
+                        float value) {
+        if (actions.size() != priors.size()) throw std::range_error("expand: actions and priors differ in length");
+        ts.expand(thread, actions.data(), priors.data(), (int)actions.size(), value);
+      })
+      .def("done", &TreeSearch::done)
+      .def("best_action", [](const TreeSearch& ts, unsigned seed) { std::mt19937 r(seed); return ts.best_action(&r); },
+           py::arg("seed") = 1u)
+      .def("root_edges", &TreeSearch::root_edges)
+      .def("num_nodes", &TreeSearch::num_nodes)
+      .def("seq_of", &TreeSearch::seq_of)
+      .def("bump_seq", &TreeSearch::bump_seq);
 
   // host-side helpers exposed for tests and tools
   m.def("parse_sgf", [](const std::string& text) {

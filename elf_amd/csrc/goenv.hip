@@ -685,6 +685,52 @@ __global__ __launch_bounds__(128) void k_copy_boards(BoardRec* state, int n_tota
   for (int i = threadIdx.x; i < (int)(sizeof(BoardRec) / 16); i += blockDim.x) out[i] = in[i];
 }
 
+// The k legal points of largest policy weight, in descending order: what DirectPredictAI::get_last_pi
+// (go/go_ai.h:24-68) hands to the tree search (it sorts all 361 by pi and keeps the first five that
+// pass CheckMove).  One wavefront per board; k rounds of a wave-wide arg-max over the legal
+// ballots (ties: lowest point index; the reference's std::sort leaves them unspecified).
+__global__ __launch_bounds__(64) void k_topk_policy(const BoardRec* state, int n_total, const int32_t* idx, int first,
+                                                    int n, const float* pi, const int32_t* aug_codes, int k,
+                                                    int32_t* actions_out, float* probs_out) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= n) return;
+  const int board = board_of(idx, first, n_total, b);
+  Masks m;
+  if (board >= 0) load_masks(state + board, m);
+  const int aug = aug_codes ? (aug_codes[b] & 7) : 0;
+  const float* row = pi + (size_t)b * NPTS;
+  float v[NWORDS];
+  bool live[NWORDS];
+  GO_UNROLL
+  for (int j = 0; j < NWORDS; ++j) {
+    const int p = lane + 64 * j;
+    live[j] = board >= 0 && p < NPTS && ((m.legal[j] >> lane) & 1ull);
+    v[j] = live[j] ? row[aug ? d4_dest(aug, p) : p] : 0.f;
+    if (v[j] != v[j]) live[j] = false;  // NaN weights never compare: leave them out
+  }
+  for (int r = 0; r < k; ++r) {  // host-checked bound
+    // lane-local best, then a wave reduction on (value, lowest point)
+    float best = 0.f;
+    int bp = -1;
+    GO_UNROLL
+    for (int j = 0; j < NWORDS; ++j)
+      if (live[j] && (bp < 0 || v[j] > best)) { best = v[j]; bp = lane + 64 * j; }
+    GO_UNROLL
+    for (int d = 32; d >= 1; d >>= 1) {
+      const float ob = __shfl_xor(best, d);
+      const int op = __shfl_xor(bp, d);
+      if (op >= 0 && (bp < 0 || ob > best || (ob == best && op < bp))) { best = ob; bp = op; }
+    }
+    if (lane == 0) {
+      actions_out[(size_t)b * k + r] = bp;
+      if (probs_out) probs_out[(size_t)b * k + r] = bp >= 0 ? best : 0.f;
+    }
+    GO_UNROLL
+    for (int j = 0; j < NWORDS; ++j)
+      if (bp == lane + 64 * j) live[j] = false;
+  }
+}
+
 // Heuristic move filters (goenv_tactics.h): always one wavefront per board -- the work is either
 // per point (one pass) or a played-out line (serial), neither gains from more waves.
 __global__ __launch_bounds__(64) void k_tactics(const BoardRec* state, int n_total, const int32_t* idx, int first,
@@ -1006,6 +1052,18 @@ int goenv_sample_policy(goenv_ctx* c, const int32_t* idx, int first, int count, 
   if (count == 0) return 0;
   hipLaunchKernelGGL(k_sample_policy, dim3(count), dim3(64), 0, S(stream), c->state, c->n, idx, first, count, pi,
                      aug_codes, actions_out, c->seed, c->id_base);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int goenv_topk_policy(goenv_ctx* c, const int32_t* idx, int first, int count, const float* pi,
+                      const int32_t* aug_codes, int k, int32_t* actions_out, float* probs_out, void* stream) {
+  if (check_sel(c, idx, first, count, "goenv_topk_policy")) return -1;
+  if (!pi || !actions_out) return fail("goenv_topk_policy: pi and actions_out are required");
+  if (k < 1 || k > GOENV_NUM_POINTS) return fail("goenv_topk_policy: k must be in 1..361");
+  if (count == 0) return 0;
+  hipLaunchKernelGGL(k_topk_policy, dim3(count), dim3(64), 0, S(stream), c->state, c->n, idx, first, count, pi,
+                     aug_codes, k, actions_out, probs_out);
   HIPCHK(hipGetLastError());
   return 0;
 }

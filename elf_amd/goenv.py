@@ -69,6 +69,8 @@ _SIGS = {
     "goenv_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goenv_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goenv_fast_score": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "goenv_topk_policy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
     "goenv_tactics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "goenv_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
     "goenv_stats_ptr": (C.c_void_p, [C.c_void_p]),
@@ -324,6 +326,15 @@ class GoEnv:
     def fast_score(self, rule, out):
         self._check(out, torch.float32, (self.n,), "out")
         self._chk(self.lib.goenv_fast_score(self._h, int(rule), _ptr(out), self._stream()))
+
+    def topk_policy(self, pi, k, actions_out, probs_out=None, aug_codes=None, idx=None, first=0, count=None):
+        ip, first, count = self._sel(idx, first, count)
+        self._check(pi, torch.float32, (count, NUM_POINTS), "pi")
+        self._check(actions_out, torch.int32, (count, k), "actions_out")
+        self._check(probs_out, torch.float32, (count, k), "probs_out")
+        self._check(aug_codes, torch.int32, (count,), "aug_codes")
+        self._chk(self.lib.goenv_topk_policy(self._h, ip, first, count, _ptr(pi), _ptr(aug_codes), int(k),
+                                             _ptr(actions_out), _ptr(probs_out), self._stream()))
 
     def tactics(self, self_atari_thres=1, idx=None, first=0, count=None, **outs):
         """goenv_tactics: outs = self_atari / gives_ko / cand / libs / ladder tensors ([count, 361],

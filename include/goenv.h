@@ -241,6 +241,16 @@ int goenv_collect_sel(goenv_ctx* ctx, const int32_t* idx, int first, int count,
 int goenv_sample_policy(goenv_ctx* ctx, const int32_t* idx, int first, int count, const float* pi,
                         const int32_t* aug_codes, int64_t* actions_out, void* stream);
 
+/* goenv_topk_policy: the k legal points of largest policy weight of every selected board, in
+ * descending order -- what DirectPredictAI::get_last_pi (go/go_ai.h:24-68) gives the tree search
+ * (k = 5 there: all 361 sorted by pi, the first five that pass CheckMove kept).  pi float32
+ * [count][361], indexed in the frame of aug_codes (int32 [count] or NULL = 0); actions_out int32
+ * [count][k] board points p = x*19+y (-1 once the legal points run out); probs_out float32
+ * [count][k] their weights (may be NULL).  Ties go to the lower point (the reference's std::sort
+ * leaves them unspecified); NaN weights are skipped. */
+int goenv_topk_policy(goenv_ctx* ctx, const int32_t* idx, int first, int count, const float* pi,
+                      const int32_t* aug_codes, int k, int32_t* actions_out, float* probs_out, void* stream);
+
 /* goenv_get_state_sel: goenv_get_state for a selection (rows = selection rows). */
 int goenv_get_state_sel(goenv_ctx* ctx, const int32_t* idx, int first, int count, uint8_t* color,
                         int16_t* liberties, int16_t* stones, uint16_t* last_placed, int32_t* scalars,

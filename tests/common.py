@@ -92,3 +92,14 @@ def dump_json(path, obj):
     with open(path, "w") as f:
         json.dump(obj, f, separators=(",", ":"))
         f.write("\n")
+
+
+def mcts_policy(s):
+    """Deterministic stand-in for the policy/value net of the tree-search tests: a function of the
+    25 planes alone.  pi is a permutation of 1..361 (all weights distinct, so the reference's
+    unstable sort has no ties), normalised in float32; V in [0, 1)."""
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(np.ascontiguousarray(s, np.float32).tobytes()) & 0x7FFFFFFF)
+    pi = (rs.permutation(361) + 1).astype(np.float32)
+    pi /= np.float32(pi.sum())
+    return pi, np.float32(rs.rand())
