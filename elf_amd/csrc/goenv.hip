@@ -801,6 +801,9 @@ struct goenv_ctx {
   int nw;  // waves per board: 0 = by batch size, else 1 / 2 / 3 / 6
   int zero_first;  // -1 = by batch size, 0 / 1 pinned (GOENV_ZERO_FIRST, tuning only)
   float lut1;
+  hipStream_t part_stream[GOENV_MAX_PARTS];  // goenv_ply_repeat_parts; created on first use
+  hipEvent_t part_event[GOENV_MAX_PARTS + 1];
+  int parts_ready;
 };
 
 // The standalone feature kernel has no rules phase that staggers its waves' stores: mid-size
@@ -911,6 +914,10 @@ int goenv_destroy(goenv_ctx* c) {
   (void)hipFree(c->lut);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
+  if (c->parts_ready) {
+    for (int i = 0; i < GOENV_MAX_PARTS; ++i) (void)hipStreamDestroy(c->part_stream[i]);
+    for (int i = 0; i <= GOENV_MAX_PARTS; ++i) (void)hipEventDestroy(c->part_event[i]);
+  }
   delete c;
   return 0;
 }
@@ -1005,6 +1012,46 @@ int goenv_ply_repeat(goenv_ctx* c, int n_steps, uint32_t flags, const int64_t* a
   for (int i = 0; i < n_steps; ++i) {
     const int rc = goenv_ply(c, flags, actions, aug_codes, feat_out, legal_out, actions_out, status_out, stream);
     if (rc) return rc;
+  }
+  return 0;
+}
+
+// n_steps plies of every board with the batch cut into n_parts contiguous parts, each part a
+// launch sequence of its own on a stream of its own: the parts drift out of phase, so the
+// latency-bound front of one part's launch (launch, record round trip, rules) runs under the
+// store drain of another's.  Fork / join around the whole sequence on the caller's stream.
+int goenv_ply_repeat_parts(goenv_ctx* c, int n_steps, int n_parts, uint32_t flags, const int64_t* actions,
+                           const int32_t* aug_codes, float* feat_out, uint8_t* legal_out, int32_t* actions_out,
+                           int32_t* status_out, void* stream) {
+  if (!c) return fail("goenv_ply_repeat_parts: ctx is NULL");
+  if (n_steps < 0) return fail("goenv_ply_repeat_parts: n_steps is negative");
+  if (n_parts < 1 || n_parts > GOENV_MAX_PARTS || n_parts > c->n)
+    return fail("goenv_ply_repeat_parts: n_parts must be in 1..min(GOENV_MAX_PARTS, boards)");
+  if (n_parts == 1) return goenv_ply_repeat(c, n_steps, flags, actions, aug_codes, feat_out, legal_out, actions_out,
+                                            status_out, stream);
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->parts_ready) {
+    for (int i = 0; i < GOENV_MAX_PARTS; ++i) HIPCHK(hipStreamCreateWithFlags(&c->part_stream[i], hipStreamNonBlocking));
+    for (int i = 0; i <= GOENV_MAX_PARTS; ++i) HIPCHK(hipEventCreateWithFlags(&c->part_event[i], hipEventDisableTiming));
+    c->parts_ready = 1;
+  }
+  HIPCHK(hipEventRecord(c->part_event[GOENV_MAX_PARTS], S(stream)));
+  for (int p = 0; p < n_parts; ++p) HIPCHK(hipStreamWaitEvent(c->part_stream[p], c->part_event[GOENV_MAX_PARTS], 0));
+  for (int i = 0; i < n_steps; ++i) {
+    for (int p = 0; p < n_parts; ++p) {
+      const int first = (int)((long long)c->n * p / n_parts), last = (int)((long long)c->n * (p + 1) / n_parts);
+      const int rc = goenv_ply_sel(c, nullptr, first, last - first, flags & ~GOENV_F_COLLECT,
+                                   actions ? actions + first : nullptr, aug_codes ? aug_codes + first : nullptr,
+                                   feat_out ? feat_out + (size_t)first * GOENV_FEAT_FLOATS : nullptr,
+                                   legal_out ? legal_out + (size_t)first * GOENV_NUM_POINTS : nullptr, nullptr,
+                                   actions_out ? actions_out + first : nullptr, status_out ? status_out + first : nullptr,
+                                   c->part_stream[p]);
+      if (rc) return rc;
+    }
+  }
+  for (int p = 0; p < n_parts; ++p) {
+    HIPCHK(hipEventRecord(c->part_event[p], c->part_stream[p]));
+    HIPCHK(hipStreamWaitEvent(S(stream), c->part_event[p], 0));
   }
   return 0;
 }

@@ -727,8 +727,12 @@ __device__ __forceinline__ void store4(float* p, float a, float b, float c, floa
   return;
 #endif
   if (WT) {
+    // The two wait states after the store are part of the instruction as far as the compiler is
+    // concerned: a VMEM store of more than 64 bits must not be followed at once by a VALU write to
+    // its data registers (the store would pick up the new value), and the hazard recogniser does
+    // not look inside inline asm.  Without them about one board-ply in a thousand had one wrong float.
     const f32x4 v = {a, b, c, d};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v));
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v));
   } else {
     const float4u v = {a, b, c, d};
     *reinterpret_cast<float4u*>(p) = v;

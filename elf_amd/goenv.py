@@ -51,6 +51,7 @@ _SIGS = {
     "goenv_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goenv_ply": (C.c_int, [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6 + [C.c_void_p]),
     "goenv_ply_repeat": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32] + [C.c_void_p] * 6 + [C.c_void_p]),
+    "goenv_ply_repeat_parts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32] + [C.c_void_p] * 6 + [C.c_void_p]),
     "goenv_ply_sel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32] + [C.c_void_p] * 8),
     "goenv_collect_sel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5),
     "goenv_sample_policy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4),
@@ -246,6 +247,18 @@ class GoEnv:
         self._chk(self.lib.goenv_ply_repeat(self._h, int(n_steps), flags, _ptr(actions), _ptr(aug_codes),
                                             _ptr(feat_out), _ptr(legal_out), _ptr(actions_out), _ptr(status_out),
                                             self._stream()))
+
+    def ply_repeat_parts(self, n_steps, n_parts, flags=0, actions=None, aug_codes=None, feat_out=None, legal_out=None,
+                         actions_out=None, status_out=None):
+        self._check(actions, torch.int64, (self.n,), "actions")
+        self._check(aug_codes, torch.int32, (self.n,), "aug_codes")
+        self._check(feat_out, torch.float32, (self.n, NUM_PLANES, 19, 19), "feat_out")
+        self._check(legal_out, torch.uint8, (self.n, NUM_POINTS), "legal_out")
+        self._check(actions_out, torch.int32, (self.n,), "actions_out")
+        self._check(status_out, torch.int32, (self.n,), "status_out")
+        self._chk(self.lib.goenv_ply_repeat_parts(self._h, int(n_steps), int(n_parts), flags, _ptr(actions),
+                                                  _ptr(aug_codes), _ptr(feat_out), _ptr(legal_out), _ptr(actions_out),
+                                                  _ptr(status_out), self._stream()))
 
     def _sel(self, idx, first, count):
         if idx is not None:

@@ -215,6 +215,18 @@ int goenv_ply_repeat(goenv_ctx* ctx, int n_steps, uint32_t flags, const int64_t*
                      const int32_t* aug_codes, float* feat_out, uint8_t* legal_out, int32_t* actions_out,
                      int32_t* status_out, void* stream);
 
+/* goenv_ply_repeat_parts: as goenv_ply_repeat, with the batch cut into n_parts (1..GOENV_MAX_PARTS)
+ * contiguous parts that are stepped on streams of their own (the library's), forked from and
+ * joined to `stream` around the whole sequence.  Every board gets exactly n_steps plies and the
+ * results equal goenv_ply_repeat's; the parts are not in step with each other in between, so
+ * the front of one part's launch (launch latency, record round trip, rules) runs under the
+ * store drain of another's.  The counterpart in the reference is its set of collectors, each
+ * batching whichever games are ready (elf/comm_template.h:170-181, num_collectors). */
+#define GOENV_MAX_PARTS 8
+int goenv_ply_repeat_parts(goenv_ctx* ctx, int n_steps, int n_parts, uint32_t flags, const int64_t* actions,
+                           const int32_t* aug_codes, float* feat_out, uint8_t* legal_out, int32_t* actions_out,
+                           int32_t* status_out, void* stream);
+
 /* Selections.  The three calls below act on `count` boards: board of row b is
  * idx[b] (device int32) when idx != NULL, else first + b.  Every batch array is
  * indexed by the ROW b, so a collector's batch tensors can be filled from any

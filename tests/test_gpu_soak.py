@@ -1,0 +1,65 @@
+"""GPU soak: EVERY float of every board's planes and every legal-mask byte, on every ply, for the
+launch shapes the benchmark uses (1,024 boards: three waves per board + write-through stores;
+2,048 boards: plain stores), against oracle boards replaying the same moves.  ~250,000 board-plies:
+a fault that corrupts one float in a thousand board-plies (an unguarded store-data hazard behind the
+inline-asm write-through store did exactly that) cannot hide here."""
+import numpy as np
+import pytest
+
+from oracle.pyoracle import OracleBoard
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.mark.parametrize("boards,plies,parts", [(1024, 120, 1), (2048, 40, 1), (1024, 60, 2)])
+def test_all_planes_of_all_boards_every_ply(boards, plies, parts):
+    from elf_amd import goenv
+    goenv.load_library()
+    env = goenv.GoEnv(boards, seed=17, max_ply=722)
+    feat = env.new(torch.float32, 25, 19, 19)
+    legal = env.new(torch.uint8, 361)
+    acts = env.new(torch.int32)
+    oracles = [OracleBoard() for _ in range(boards)]
+    flags = goenv.F_RANDOM_POLICY | goenv.F_AUTO_RESTART
+    bad = 0
+    for t in range(plies):
+        feat.fill_(-3.0)
+        env.ply_repeat_parts(1, parts, flags, feat_out=feat, legal_out=legal, actions_out=acts)
+        f = feat.cpu().numpy().reshape(boards, -1)
+        lg = legal.cpu().numpy()
+        for b, a in enumerate(acts.cpu().tolist()):
+            o = oracles[b]
+            assert o.forward(a)[0]
+            if not np.array_equal(f[b], o.extract(0)) or not np.array_equal(lg[b], o.legal()):
+                bad += 1
+    assert bad == 0, "%d of %d board-plies differ from the oracle" % (bad, boards * plies)
+    env.close()
+
+
+def test_parts_give_the_same_boards_as_one_launch_sequence():
+    from elf_amd import goenv
+    goenv.load_library()
+    flags = goenv.F_RANDOM_POLICY | goenv.F_AUTO_RESTART
+    ref = None
+    for parts in (1, 2, 3, 8):
+        env = goenv.GoEnv(777, seed=4, max_ply=300)
+        feat = env.new(torch.float32, 25, 19, 19)
+        legal = env.new(torch.uint8, 361)
+        env.ply_repeat_parts(650, parts, flags, feat_out=feat, legal_out=legal)
+        torch.cuda.synchronize()
+        st = {k: v.cpu() for k, v in env.get_state().items()}
+        st["feat"], st["legal"], st["stats"] = feat.cpu(), legal.cpu(), torch.tensor(env.stats())
+        env.close()
+        if ref is None:
+            ref = st
+            assert int(ref["stats"][0]) > 0            # games finished and restarted on the way
+        else:
+            for k in ref:
+                assert torch.equal(ref[k], st[k]), (parts, k)
+    env = goenv.GoEnv(4, seed=1)
+    with pytest.raises(goenv.GoEnvError):
+        env.ply_repeat_parts(1, 9, flags)
+    with pytest.raises(goenv.GoEnvError):
+        env.ply_repeat_parts(1, 5, flags)               # more parts than boards
+    env.close()
