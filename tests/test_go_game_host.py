@@ -93,8 +93,15 @@ def test_errors_are_python_exceptions(go):
     with pytest.raises(Exception, match="wait_batch error"):        # state_collector.h:79-81
         gc.WaitGroup(0, 0)
     gc.Steps(go.Infos())                                            # gid -1: ignored (comm_template.h:270)
-    with pytest.raises(Exception, match="use_mcts"):
-        make_gc(go, use_mcts=True)
+    with pytest.raises(Exception, match="use_mcts"):                # no tree search in this context
+        gc.SearchInfo(0)
+    co = go.ContextOptions()
+    co.num_games = 2
+    co.mcts_options.persistent_tree = True                          # the one tree-search option not carried over
+    opt = go.GameOptions()
+    opt.mode, opt.seed, opt.use_mcts = "selfplay", 3, True
+    with pytest.raises(Exception, match="persistent_tree"):
+        go.GameContext(co, opt)
 
 
 def test_sgf_reader_matches_the_reference_on_the_corpus(go):
