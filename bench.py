@@ -1,24 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- 19x19 Go moves/s of the MI355X batched Go environment (BASELINE.json metric).
 
-A "step" is ONE fused ply of the hot path over the whole batch resident in HBM: on-device
-cfg-2 policy (uniform over legal moves that do not fill an own true eye) -> rules update
-(TryPlay/Play) -> legal mask -> 25 feature planes written into the device batch buffers, one
-kernel launch.  Finished games are scored, counted into the stats vector and restarted in place
-(as ELF's selfplay restarts games, go/game.cc:81-90), so every step applies exactly one move on
-every board and value = n_gpus * boards * steps / time.
+A "step" is ONE ply of the hot path over the whole batch resident in HBM: on-device cfg-2 policy
+(uniform over legal moves that do not fill an own true eye) -> rules update (TryPlay/Play) ->
+legal mask -> 25 feature planes, all written into device batch buffers.  Finished games are
+scored, counted into the stats vector and restarted in place (as ELF's selfplay restarts games,
+go/game.cc:81-90), so every step applies exactly one move on every board and
+value = n_gpus * boards * steps / time.
+
+The timed path is the persistent generator (goenv_generate, kernel k_generate): one launch plays
+T plies of every board with the boards kept in LDS/registers and writes ply t's planes, mask and
+move to slot t of ring buffers -- nothing is skipped against a launch per ply (same bytes, same
+order; tests/test_gpu_entry_points.py holds the two paths bit-identical).  --steps K is cut into
+K/T equal launches (T = the largest divisor of K within the ring depth).  The launch-per-ply path
+(goenv_ply, what a model in the loop uses) is timed beside it under "extra".
 
 Workload at N=1: BASELINE.json configs[1] -- 1,024 concurrent games, uniform-random legal-move
 playouts to the end, 1 MI355X.  For N>1 every rank runs the same per-GPU batch (weak scaling),
 boards keyed by global id; the only collective is the end-of-run stats all-reduce (RCCL).
 
-    python bench.py --gpus N --steps K --warmup W [--boards B]
+    python bench.py --gpus N --steps K --warmup W [--boards B] [--ring R]
 """
 import argparse
 import json
 import os
 import sys
 import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -29,7 +38,9 @@ import torch.distributed as dist  # noqa: E402
 ALG_BYTES_PLANES = 25 * 361 * 4          # float32 planes written per board per ply
 ALG_BYTES_LEGAL = 361                    # u8 legal mask written per board per ply
 REC_BYTES = 1632                         # packed board record: read once + written once per ply
-ALG_BYTES_PER_BOARD = ALG_BYTES_PLANES + ALG_BYTES_LEGAL + 2 * REC_BYTES
+ALG_BYTES_MOVE = 4                       # int32 move written per board per ply (generator)
+ALG_BYTES_PER_BOARD = ALG_BYTES_PLANES + ALG_BYTES_LEGAL + 2 * REC_BYTES      # launch per ply
+ALG_BYTES_PER_BOARD_PLY = ALG_BYTES_PLANES + ALG_BYTES_LEGAL + ALG_BYTES_MOVE  # generator, per ply
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -51,36 +62,58 @@ def cpu_baseline(budget_sec=12.0):
     }
 
 
-def measured_traffic(boards):
-    """HBM bytes per launch from the PMC passes of this round (FETCH_SIZE x2 + WRITE_SIZE, corrected
-    as MI355X_MICROARCH.md prescribes; collected by tools/profile_round.sh on the same command and
-    committed as profiles/r01_pmc.json).  None when no pass exists for this batch size."""
+def measured_traffic(boards, plies_per_launch):
+    """HBM bytes per launch of the generator kernel from the PMC passes of this round (FETCH_SIZE x2 +
+    WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes; collected by tools/profile_round.sh on
+    this same command and committed as profiles/r01_pmc.json), scaled to this run's plies per launch
+    (the kernel writes the same bytes for every ply).  None when no pass exists for this batch size."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
             d = json.load(f)
-        return float(d["traffic_bytes"]) if int(d["boards"]) == boards else None
+        if int(d["boards"]) != boards or "k_generate" not in d["kernel"]:
+            return None
+        return float(d["traffic_bytes"]) * plies_per_launch / float(d["plies_per_launch"])
     except (OSError, ValueError, KeyError):
         return None
+
+
+def plies_per_launch(steps, ring):
+    """Plies per timed launch: the largest divisor of `steps` within the ring depth, so that equal
+    launches cover EXACTLY `steps`; when `steps` has no divisor above half the ring (a prime, say)
+    the launches are `ring` plies each and the last one is shorter."""
+    t = max(t for t in range(1, min(ring, steps) + 1) if steps % t == 0)
+    return t if 2 * t >= min(ring, steps) else min(ring, steps)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--boards", type=int, default=1024, help="boards per GPU (cfg 2: 1024; cfg 4 shard: 8192)")
+    ap.add_argument("--ring", type=int, default=64, help="ring depth in plies = most plies per generator launch")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
+    if args.steps < 1 or args.warmup < 0 or args.ring < 1 or args.boards < 1:
+        ap.error("--steps, --ring and --boards must be positive, --warmup non-negative")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # GOENV_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (ranks
+    # share the cards round-robin); the driver's runs use the default, nccl = RCCL, one rank per GPU
+    backend = os.environ.get("GOENV_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world:
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run "
@@ -94,14 +127,19 @@ def main():
     torch.cuda.set_device(local_rank)
     B = args.boards
     env = goenv.GoEnv(B, device=local_rank, seed=args.seed, board_id_base=rank * B, komi=7.5, max_ply=722)
-    feat = env.new(torch.float32, 25, 19, 19)
-    legal = env.new(torch.uint8, 361)
-    flags = goenv.F_RANDOM_POLICY | goenv.F_AUTO_RESTART
+    T = plies_per_launch(args.steps, args.ring)
+    R = max(T, min(args.ring, max(args.warmup, 1)))
+    feat = torch.empty(R, B, 25, 19, 19, dtype=torch.float32, device=env.device)   # ring: slot t = ply t of a launch
+    legal = torch.empty(R, B, 361, dtype=torch.uint8, device=env.device)
+    moves = torch.empty(R, B, dtype=torch.int32, device=env.device)
 
-    def steps(k):
-        # k launches of the fused ply, enqueued back to back from native code (goenv_ply_repeat):
-        # the timed region then holds GPU work only, whatever the speed of the Python host
-        env.ply_repeat(k, flags, feat_out=feat, legal_out=legal)
+    def steps(k, per):
+        # k plies of every board as launches of `per` plies of the persistent generator (the last
+        # one shorter if `per` does not divide k -- warmup only); launches queue back to back
+        while k > 0:
+            t = min(per, k)
+            env.generate(t, feat[:t], legal[:t], moves[:t])
+            k -= t
 
     def sync():
         torch.cuda.synchronize()
@@ -109,14 +147,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    steps(args.warmup)
+    steps(args.warmup, R)
     sync()
     env.timer_begin()
     t0 = time.perf_counter()
-    steps(args.steps)
+    steps(args.steps, T)
     env.timer_end()
     torch.cuda.synchronize()
-    kernel_ms = env.timer_ms() / args.steps          # HIP events on the launch stream
+    launches = -(-args.steps // T)
+    kernel_ms = env.timer_ms() / launches            # HIP events on the launch stream; average launch
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -129,32 +168,39 @@ def main():
     stats = reduce_stats(env.stats_tensor()).cpu().tolist()
 
     value = world * B * args.steps / elapsed
-    achieved = B * ALG_BYTES_PER_BOARD / (kernel_ms * 1e-3) / 1e9
+    alg_launch = B * (args.steps / launches * ALG_BYTES_PER_BOARD_PLY + 2 * REC_BYTES)   # average launch
+    achieved = alg_launch / (kernel_ms * 1e-3) / 1e9
     out = {
         "metric": "19x19 Go moves/sec (node, 1/2/4/8 GPU) + feature-extract HBM GB/s",
         "value": value, "unit": "moves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "i32", "data": "synthetic",
         "config": {"workload": "cfg2: %d concurrent 19x19 games per GPU, on-device uniform-random legal-move "
-                               "playouts to the end (restart in place), fused step + legal mask + 25 planes "
-                               "per ply" % B,
-                   "boards_per_gpu": B, "global_boards": world * B, "ply_cap": 722, "parallelism": "shard%d" % world},
-        "roofline": {"bound": "hbm", "kernel": "k_ply<random>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B),
+                               "playouts to the end (scored, counted, restarted in place); every ply of every "
+                               "board = rules update + legal mask + 25 planes + the move, written to slot t of "
+                               "device ring buffers by the persistent generator (goenv_generate, %d plies per "
+                               "launch)" % (B, T),
+                   "boards_per_gpu": B, "global_boards": world * B, "ply_cap": 722,
+                   "plies_per_launch": args.steps / launches, "launches": launches, "parallelism": "shard%d" % world, "collective_backend": backend if world > 1 else None},
+        "roofline": {"bound": "hbm", "kernel": "k_generate", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B, args.steps / launches),
                      "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc.md)",
-                     "algorithmic_bytes_per_launch": B * ALG_BYTES_PER_BOARD,
-                     "bytes_per_board": ALG_BYTES_PER_BOARD, "kernel_ms": kernel_ms},
+                     "algorithmic_bytes_per_launch": alg_launch,
+                     "bytes_per_board_ply": ALG_BYTES_PER_BOARD_PLY, "record_bytes_per_board_launch": 2 * REC_BYTES,
+                     "kernel_ms": kernel_ms},
         "feature_extract_GBps": achieved,
         "stats": {"games": stats[0], "black_wins": stats[1], "white_wins": stats[2], "plies": stats[4],
                   "max_len": stats[9], "ply_cap_hits": stats[8]},
     }
+    env.close()
+    del feat, legal, moves
+    torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.no_extra:
         out["extra"] = extra_measurements(goenv, args.seed)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-    env.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -163,15 +209,16 @@ def main():
 
 
 def extra_measurements(goenv, seed):
-    """Not the headline: the same kernels at the cfg-4 per-GPU shard (8,192 boards) and larger,
-    the standalone feature kernel, and the persistent playout kernel."""
+    """Not the headline: the launch-per-ply path (k_ply, what a model in the loop uses) at 1,024
+    boards, at the cfg-4 per-GPU shard (8,192 boards) and at 65,536 boards, the standalone feature
+    kernel, the generator at the cfg-4 shard, and the persistent playout kernel."""
     res = {}
-    for B in (8192, 65536):
+    flags = goenv.F_RANDOM_POLICY | goenv.F_AUTO_RESTART
+    for B in (1024, 8192, 65536):
         env = goenv.GoEnv(B, seed=seed, max_ply=722)
         feat, legal = env.new(torch.float32, 25, 19, 19), env.new(torch.uint8, 361)
-        flags = goenv.F_RANDOM_POLICY | goenv.F_AUTO_RESTART
-        steps = 300 if B == 8192 else 60
-        env.ply_repeat(100 if B == 8192 else 150, flags, feat_out=feat, legal_out=legal)   # into the middle game
+        steps = {1024: 2000, 8192: 300, 65536: 60}[B]
+        env.ply_repeat(150 if B == 65536 else 100, flags, feat_out=feat, legal_out=legal)   # into the middle game
         torch.cuda.synchronize()
         env.timer_begin()
         env.ply_repeat(steps, flags, feat_out=feat, legal_out=legal)
@@ -179,6 +226,7 @@ def extra_measurements(goenv, seed):
         ms = env.timer_ms() / steps
         r = {"ply_ms": ms, "moves_per_s": B / (ms * 1e-3),
              "ply_GBps": B * ALG_BYTES_PER_BOARD / (ms * 1e-3) / 1e9}
+        steps = min(steps, 300)
         env.timer_begin()
         for _ in range(steps):
             env.features(feat, None, legal)
@@ -186,26 +234,28 @@ def extra_measurements(goenv, seed):
         ms = env.timer_ms() / steps
         r["features_ms"] = ms
         r["features_GBps"] = B * (ALG_BYTES_PLANES + ALG_BYTES_LEGAL + REC_BYTES) / (ms * 1e-3) / 1e9
-        res["boards_%d" % B] = r
+        res["launch_per_ply_%d" % B] = r
         env.close()
         del feat, legal
-    # persistent generator: 64 plies per launch into ring buffers (2.4 GB of planes: a true HBM stream)
-    env = goenv.GoEnv(1024, seed=seed, max_ply=722)
-    T = 64
-    fr = torch.zeros(T, 1024, 25, 19, 19, device=env.device)
-    lr = torch.zeros(T, 1024, 361, dtype=torch.uint8, device=env.device)
-    for _ in range(3):
-        env.generate(T, fr, lr)
+    # generator at the cfg-4 shard: 16 plies per launch (4.7 GB of planes per launch)
+    B, T = 8192, 16
+    env = goenv.GoEnv(B, seed=seed, max_ply=722)
+    fr = torch.empty(T, B, 25, 19, 19, device=env.device)
+    lr = torch.empty(T, B, 361, dtype=torch.uint8, device=env.device)
+    ar = torch.empty(T, B, dtype=torch.int32, device=env.device)
+    for _ in range(6):
+        env.generate(T, fr, lr, ar)
     torch.cuda.synchronize()
     env.timer_begin()
-    for _ in range(6):
-        env.generate(T, fr, lr)
+    for _ in range(10):
+        env.generate(T, fr, lr, ar)
     env.timer_end()
-    ms = env.timer_ms() / (6 * T)
-    res["persistent_generate_1024"] = {"ply_ms": ms, "moves_per_s": 1024 / (ms * 1e-3), "plies_per_launch": T,
-                                       "GBps": 1024 * (ALG_BYTES_PLANES + ALG_BYTES_LEGAL) / (ms * 1e-3) / 1e9}
+    ms = env.timer_ms() / (10 * T)
+    res["generate_8192"] = {"ply_ms": ms, "moves_per_s": B / (ms * 1e-3), "plies_per_launch": T,
+                            "GBps": B * ALG_BYTES_PER_BOARD_PLY / (ms * 1e-3) / 1e9}
     env.close()
-    del fr, lr
+    del fr, lr, ar
+    torch.cuda.empty_cache()
     env = goenv.GoEnv(1024, seed=seed, max_ply=722)
     nm = env.new(torch.int32)
     env.playout(None, nm)

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/goenv.h"
 #include "goenv_device.h"
@@ -854,6 +855,30 @@ static int fail(const char* what, hipError_t e = hipSuccess) {
 
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
+// Entry points that launch or copy run with the context's device current and put the caller's
+// device back on return (one host thread may drive several GPUs; a kernel launched on the null
+// stream of another device would be handed pointers that device cannot reach).
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err;
+  explicit DeviceScope(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) {
+      err = hipSetDevice(dev);
+      switched = err == hipSuccess;
+    }
+  }
+  ~DeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+#define ON_DEVICE_OF(c)                       \
+  DeviceScope dev_scope_((c)->device);        \
+  if (dev_scope_.err != hipSuccess) return fail("selecting the context's device", dev_scope_.err)
+
 extern "C" {
 
 int goenv_version(void) { return 1; }
@@ -868,8 +893,9 @@ int goenv_create(int device, int n_boards, uint64_t seed, int64_t board_id_base,
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail("goenv_create: no such HIP device");
-  HIPCHK(hipSetDevice(device));
-  goenv_ctx* c = new goenv_ctx();
+  DeviceScope scope(device);
+  if (scope.err != hipSuccess) return fail("goenv_create: hipSetDevice", scope.err);
+  goenv_ctx* c = new goenv_ctx();  // value-initialised: every pointer and handle starts as zero
   c->device = device; c->n = n_boards; c->seed = seed; c->id_base = board_id_base;
   c->komi = komi; c->max_ply = max_ply; c->nw = 0; c->zero_first = -1;
   if (const char* e = getenv("GOENV_ZERO_FIRST")) c->zero_first = atoi(e) & 3;
@@ -877,37 +903,42 @@ int goenv_create(int device, int n_boards, uint64_t seed, int64_t board_id_base,
     const int v = atoi(e);
     if (v == 1 || v == 2 || v == 3 || v == 6) c->nw = v;
   }
-  c->state = nullptr; c->stats = nullptr; c->lut = nullptr;
-  hipError_t e;
-  if ((e = hipMalloc((void**)&c->state, (size_t)n_boards * sizeof(BoardRec))) != hipSuccess ||
-      (e = hipMalloc((void**)&c->stats, GOENV_NUM_STATS * sizeof(unsigned long long))) != hipSuccess ||
-      (e = hipMalloc((void**)&c->lut, HIST_LUT_N * sizeof(float))) != hipSuccess) {
-    if (c->state) (void)hipFree(c->state);
-    if (c->stats) (void)hipFree(c->stats);
-    delete c;
-    return fail("goenv_create: hipMalloc", e);
-  }
   // GetHistoryExp, go/board_feature.cc:141: exp((last_placed - ply) / 10.0) in double, narrowed to
   // float -- evaluated on the host with the same libm call so no device exp rounding enters.
-  static float lut[HIST_LUT_N];
+  std::vector<float> lut(HIST_LUT_N);
   for (int d = 0; d < HIST_LUT_N; ++d) lut[d] = (float)exp((double)(-d) / 10.0);
   lut[HIST_LUT_N - 1] = 0.f;  // ages >= 2047 plies: exp(-204.7) underflows float to 0
   c->lut1 = lut[1];
-  HIPCHK(hipMemcpy(c->lut, lut, sizeof(lut), hipMemcpyHostToDevice));
-  HIPCHK(hipMemset(c->stats, 0, GOENV_NUM_STATS * sizeof(unsigned long long)));
-  HIPCHK(hipMemset(c->state, 0, (size_t)n_boards * sizeof(BoardRec)));
-  HIPCHK(hipEventCreate(&c->ev0));
-  HIPCHK(hipEventCreate(&c->ev1));
-  GO_LAUNCH(pick_nw(c, n_boards), k_reset, n_boards, 0, c->state, n_boards, nullptr, n_boards, nullptr);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipDeviceSynchronize());
+  hipError_t e;
+  const char* what = "goenv_create: hipMalloc";
+  if ((e = hipMalloc((void**)&c->state, (size_t)n_boards * sizeof(BoardRec))) == hipSuccess &&
+      (e = hipMalloc((void**)&c->stats, GOENV_NUM_STATS * sizeof(unsigned long long))) == hipSuccess &&
+      (e = hipMalloc((void**)&c->lut, HIST_LUT_N * sizeof(float))) == hipSuccess) {
+    what = "goenv_create: initialising the boards";
+    if ((e = hipMemcpy(c->lut, lut.data(), HIST_LUT_N * sizeof(float), hipMemcpyHostToDevice)) == hipSuccess &&
+        (e = hipMemset(c->stats, 0, GOENV_NUM_STATS * sizeof(unsigned long long))) == hipSuccess &&
+        (e = hipMemset(c->state, 0, (size_t)n_boards * sizeof(BoardRec))) == hipSuccess &&
+        (e = hipEventCreate(&c->ev0)) == hipSuccess && (e = hipEventCreate(&c->ev1)) == hipSuccess) {
+      GO_LAUNCH(pick_nw(c, n_boards), k_reset, n_boards, 0, c->state, n_boards, nullptr, n_boards, nullptr);
+      if ((e = hipGetLastError()) == hipSuccess) e = hipDeviceSynchronize();
+    }
+  }
+  if (e != hipSuccess) {  // nothing of a half-built context is left behind
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->state) (void)hipFree(c->state);
+    if (c->stats) (void)hipFree(c->stats);
+    if (c->lut) (void)hipFree(c->lut);
+    delete c;
+    return fail(what, e);
+  }
   *out = c;
   return 0;
 }
 
 int goenv_destroy(goenv_ctx* c) {
   if (!c) return 0;
-  (void)hipSetDevice(c->device);
+  DeviceScope scope(c->device);
   (void)hipDeviceSynchronize();
   (void)hipFree(c->state);
   (void)hipFree(c->stats);
@@ -935,6 +966,7 @@ void* goenv_state_ptr(goenv_ctx* c) { return c ? (void*)c->state : nullptr; }
 
 int goenv_reset(goenv_ctx* c, const int32_t* idx, int n, const int32_t* handicap, void* stream) {
   if (!c) return fail("goenv_reset: ctx is NULL");
+  ON_DEVICE_OF(c);
   const int cnt = idx ? n : c->n;
   if (cnt <= 0) return idx ? 0 : fail("goenv_reset: empty context");
   if (idx && n > c->n) return fail("goenv_reset: n exceeds the number of boards");
@@ -946,6 +978,7 @@ int goenv_reset(goenv_ctx* c, const int32_t* idx, int n, const int32_t* handicap
 int goenv_get_state(goenv_ctx* c, uint8_t* color, int16_t* liberties, int16_t* stones, uint16_t* last_placed,
                     int32_t* scalars, void* stream) {
   if (!c) return fail("goenv_get_state: ctx is NULL");
+  ON_DEVICE_OF(c);
   GO_LAUNCH(pick_nw(c, c->n), k_get_state, c->n, S(stream), c->state, c->n, nullptr, 0, c->n, color, liberties, stones,
             last_placed, scalars);
   HIPCHK(hipGetLastError());
@@ -955,6 +988,7 @@ int goenv_get_state(goenv_ctx* c, uint8_t* color, int16_t* liberties, int16_t* s
 int goenv_set_state(goenv_ctx* c, const uint8_t* color, const uint16_t* last_placed, const int32_t* scalars,
                     void* stream) {
   if (!c) return fail("goenv_set_state: ctx is NULL");
+  ON_DEVICE_OF(c);
   if (!color || !scalars) return fail("goenv_set_state: color and scalars are required");
   GO_LAUNCH(pick_nw(c, c->n), k_set_state, c->n, S(stream), c->state, c->n, color, last_placed, scalars);
   HIPCHK(hipGetLastError());
@@ -986,6 +1020,7 @@ int goenv_ply_sel(goenv_ctx* c, const int32_t* idx, int first, int count, uint32
                   const int32_t* aug_codes, float* feat_out, uint8_t* legal_out, const goenv_sample_out* meta,
                   int32_t* actions_out, int32_t* status_out, void* stream) {
   if (check_sel(c, idx, first, count, "goenv_ply_sel")) return -1;
+  ON_DEVICE_OF(c);
   const bool random = flags & GOENV_F_RANDOM_POLICY;
   if (!random && !actions) return fail("goenv_ply: actions required unless GOENV_F_RANDOM_POLICY is set");
   if ((flags & GOENV_F_COLLECT) && !meta) return fail("goenv_ply: GOENV_F_COLLECT needs a goenv_sample_out");
@@ -1029,7 +1064,7 @@ int goenv_ply_repeat_parts(goenv_ctx* c, int n_steps, int n_parts, uint32_t flag
     return fail("goenv_ply_repeat_parts: n_parts must be in 1..min(GOENV_MAX_PARTS, boards)");
   if (n_parts == 1) return goenv_ply_repeat(c, n_steps, flags, actions, aug_codes, feat_out, legal_out, actions_out,
                                             status_out, stream);
-  HIPCHK(hipSetDevice(c->device));
+  ON_DEVICE_OF(c);
   if (!c->parts_ready) {
     for (int i = 0; i < GOENV_MAX_PARTS; ++i) HIPCHK(hipStreamCreateWithFlags(&c->part_stream[i], hipStreamNonBlocking));
     for (int i = 0; i <= GOENV_MAX_PARTS; ++i) HIPCHK(hipEventCreateWithFlags(&c->part_event[i], hipEventDisableTiming));
@@ -1076,6 +1111,7 @@ int goenv_step(goenv_ctx* c, const int64_t* actions, uint8_t* legal_out, int32_t
 int goenv_collect_sel(goenv_ctx* c, const int32_t* idx, int first, int count, const int32_t* aug_codes,
                       float* feat_out, uint8_t* legal_out, const goenv_sample_out* meta, void* stream) {
   if (check_sel(c, idx, first, count, "goenv_collect_sel")) return -1;
+  ON_DEVICE_OF(c);
   if (count == 0) return 0;
   goenv_sample_out m;
   memset(&m, 0, sizeof(m));
@@ -1095,6 +1131,7 @@ int goenv_features(goenv_ctx* c, const int32_t* aug_codes, float* feat_out, uint
 int goenv_sample_policy(goenv_ctx* c, const int32_t* idx, int first, int count, const float* pi,
                         const int32_t* aug_codes, int64_t* actions_out, void* stream) {
   if (check_sel(c, idx, first, count, "goenv_sample_policy")) return -1;
+  ON_DEVICE_OF(c);
   if (!pi || !actions_out) return fail("goenv_sample_policy: pi and actions_out are required");
   if (count == 0) return 0;
   hipLaunchKernelGGL(k_sample_policy, dim3(count), dim3(64), 0, S(stream), c->state, c->n, idx, first, count, pi,
@@ -1106,6 +1143,7 @@ int goenv_sample_policy(goenv_ctx* c, const int32_t* idx, int first, int count, 
 int goenv_topk_policy(goenv_ctx* c, const int32_t* idx, int first, int count, const float* pi,
                       const int32_t* aug_codes, int k, int32_t* actions_out, float* probs_out, void* stream) {
   if (check_sel(c, idx, first, count, "goenv_topk_policy")) return -1;
+  ON_DEVICE_OF(c);
   if (!pi || !actions_out) return fail("goenv_topk_policy: pi and actions_out are required");
   if (k < 1 || k > GOENV_NUM_POINTS) return fail("goenv_topk_policy: k must be in 1..361");
   if (count == 0) return 0;
@@ -1137,7 +1175,7 @@ int goenv_sync(void* stream) {
 
 int goenv_device_alloc(goenv_ctx* c, size_t bytes, void** out) {
   if (!c || !out) return fail("goenv_device_alloc: NULL argument");
-  HIPCHK(hipSetDevice(c->device));
+  ON_DEVICE_OF(c);
   HIPCHK(hipMalloc(out, bytes ? bytes : 1));
   return 0;
 }
@@ -1150,6 +1188,7 @@ int goenv_device_free(void* p) {
 int goenv_get_state_sel(goenv_ctx* c, const int32_t* idx, int first, int count, uint8_t* color, int16_t* liberties,
                         int16_t* stones, uint16_t* last_placed, int32_t* scalars, void* stream) {
   if (check_sel(c, idx, first, count, "goenv_get_state_sel")) return -1;
+  ON_DEVICE_OF(c);
   if (count == 0) return 0;
   GO_LAUNCH(pick_nw(c, count), k_get_state, count, S(stream), c->state, c->n, idx, first, count, color, liberties,
             stones, last_placed, scalars);
@@ -1160,6 +1199,7 @@ int goenv_get_state_sel(goenv_ctx* c, const int32_t* idx, int first, int count, 
 int goenv_replay(goenv_ctx* c, const int32_t* idx, int first, int count, const int16_t* moves, int stride,
                  const int32_t* nmoves, int32_t* napplied_out, void* stream) {
   if (check_sel(c, idx, first, count, "goenv_replay")) return -1;
+  ON_DEVICE_OF(c);
   if (!moves || !nmoves || stride <= 0) return fail("goenv_replay: moves, nmoves and a positive stride are required");
   if (count == 0) return 0;
   PlyParams P = make_params(c, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -1173,6 +1213,7 @@ int goenv_replay(goenv_ctx* c, const int32_t* idx, int first, int count, const i
 int goenv_tactics(goenv_ctx* c, const int32_t* idx, int first, int count, int self_atari_thres,
                   const goenv_tactics_out* out, void* stream) {
   if (check_sel(c, idx, first, count, "goenv_tactics")) return -1;
+  ON_DEVICE_OF(c);
   if (!out) return fail("goenv_tactics: out is NULL");
   if (self_atari_thres < 0) return fail("goenv_tactics: self_atari_thres must be >= 0");
   if (count == 0) return 0;
@@ -1188,6 +1229,7 @@ int goenv_tactics(goenv_ctx* c, const int32_t* idx, int first, int count, int se
 int goenv_copy_boards(goenv_ctx* c, const int32_t* src_idx, const int32_t* dst_idx, int n, void* stream) {
   if (!c) return fail("goenv_copy_boards: ctx is NULL");
   if (n < 0 || n > c->n) return fail("goenv_copy_boards: n out of range");
+  ON_DEVICE_OF(c);
   if (n == 0) return 0;
   if (!src_idx || !dst_idx) return fail("goenv_copy_boards: src_idx and dst_idx are required");
   hipLaunchKernelGGL(k_copy_boards, dim3(n), dim3(128), 0, S(stream), c->state, c->n, src_idx, dst_idx, n);
@@ -1208,6 +1250,7 @@ int goenv_host_free(void* p) {
 
 int goenv_playout(goenv_ctx* c, int16_t* moves_out, int max_record, int32_t* nmoves_out, void* stream) {
   if (!c) return fail("goenv_playout: ctx is NULL");
+  ON_DEVICE_OF(c);
   if (c->max_ply <= 0) return fail("goenv_playout: the context needs a ply cap (max_ply > 0)");
   if (moves_out && max_record <= 0) return fail("goenv_playout: max_record must be positive");
   PlyParams P = make_params(c, GOENV_F_RANDOM_POLICY, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -1219,6 +1262,7 @@ int goenv_playout(goenv_ctx* c, int16_t* moves_out, int max_record, int32_t* nmo
 int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* feat_ring, uint8_t* legal_ring,
                    int32_t* actions_ring, void* stream) {
   if (!c) return fail("goenv_generate: ctx is NULL");
+  ON_DEVICE_OF(c);
   if (n_plies < 0 || n_plies > (1 << 20)) return fail("goenv_generate: n_plies out of range");
   if (n_plies == 0) return 0;
   PlyParams P = make_params(c, GOENV_F_RANDOM_POLICY | GOENV_F_AUTO_RESTART, nullptr, aug_codes, feat_ring, legal_ring,
@@ -1232,6 +1276,7 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
 
 int goenv_score(goenv_ctx* c, float* score_out, float* fast_out, void* stream) {
   if (!c) return fail("goenv_score: ctx is NULL");
+  ON_DEVICE_OF(c);
   GO_LAUNCH(pick_nw(c, c->n), k_score, c->n, S(stream), c->state, c->n, score_out, fast_out, 0);
   HIPCHK(hipGetLastError());
   return 0;
@@ -1239,6 +1284,7 @@ int goenv_score(goenv_ctx* c, float* score_out, float* fast_out, void* stream) {
 
 int goenv_fast_score(goenv_ctx* c, int rule, float* out, void* stream) {
   if (!c || !out) return fail("goenv_fast_score: NULL argument");
+  ON_DEVICE_OF(c);
   if (rule != 0 && rule != 1) return fail("goenv_fast_score: rule must be 0 (Chinese) or 1 (Japanese)");
   GO_LAUNCH(pick_nw(c, c->n), k_score, c->n, S(stream), c->state, c->n, (float*)nullptr, out, rule);
   HIPCHK(hipGetLastError());
@@ -1247,6 +1293,7 @@ int goenv_fast_score(goenv_ctx* c, int rule, float* out, void* stream) {
 
 int goenv_finish(goenv_ctx* c, void* stream) {
   if (!c) return fail("goenv_finish: ctx is NULL");
+  ON_DEVICE_OF(c);
   GO_LAUNCH(pick_nw(c, c->n), k_finish, c->n, S(stream), c->state, c->n, c->stats, c->komi);
   HIPCHK(hipGetLastError());
   return 0;
@@ -1256,6 +1303,7 @@ int64_t* goenv_stats_ptr(goenv_ctx* c) { return c ? (int64_t*)c->stats : nullptr
 
 int goenv_stats_host(goenv_ctx* c, int64_t* out16_host, void* stream) {
   if (!c || !out16_host) return fail("goenv_stats_host: NULL argument");
+  ON_DEVICE_OF(c);
   HIPCHK(hipMemcpyAsync(out16_host, c->stats, GOENV_NUM_STATS * sizeof(int64_t), hipMemcpyDeviceToHost, S(stream)));
   HIPCHK(hipStreamSynchronize(S(stream)));
   return 0;
@@ -1263,22 +1311,26 @@ int goenv_stats_host(goenv_ctx* c, int64_t* out16_host, void* stream) {
 
 int goenv_stats_clear(goenv_ctx* c, void* stream) {
   if (!c) return fail("goenv_stats_clear: ctx is NULL");
+  ON_DEVICE_OF(c);
   HIPCHK(hipMemsetAsync(c->stats, 0, GOENV_NUM_STATS * sizeof(int64_t), S(stream)));
   return 0;
 }
 
 int goenv_timer_begin(goenv_ctx* c, void* stream) {
   if (!c) return fail("goenv_timer_begin: ctx is NULL");
+  ON_DEVICE_OF(c);
   HIPCHK(hipEventRecord(c->ev0, S(stream)));
   return 0;
 }
 int goenv_timer_end(goenv_ctx* c, void* stream) {
   if (!c) return fail("goenv_timer_end: ctx is NULL");
+  ON_DEVICE_OF(c);
   HIPCHK(hipEventRecord(c->ev1, S(stream)));
   return 0;
 }
 float goenv_timer_ms(goenv_ctx* c) {
   if (!c) return -1.f;
+  DeviceScope scope(c->device);
   float ms = -1.f;
   if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.f;
   if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.f;

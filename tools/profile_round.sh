@@ -8,7 +8,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-extra"
+BENCH="python3 $REPO/bench.py --steps 512 --warmup 64 --no-cpu-baseline --no-extra"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- $BENCH > $OUT/fetch_bench.json 2> $OUT/fetch.err
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- $BENCH > $OUT/write_bench.json 2> $OUT/write.err

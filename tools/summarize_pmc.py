@@ -13,9 +13,11 @@ import subprocess
 import sys
 from collections import defaultdict
 
-KERNEL = "k_ply<3, true>"
+KERNEL = "k_generate<2>"
 BOARDS = 1024
-ALGO_PER_BOARD = 36100 + 361 + 1632 + 1632   # planes + mask + record write + record read
+PLIES = 64                                   # plies per launch of the profiled command (--steps 512)
+ALGO_PER_BOARD_PLY = 36100 + 361 + 4         # planes + mask + move, per board per ply
+ALGO_PER_BOARD_LAUNCH = 1632 + 1632          # record read + record write, once per launch
 
 
 def per_launch(path):
@@ -49,22 +51,23 @@ def main():
     sq, _ = per_launch(os.path.join(src, "sq", "s_counter_collection.csv"))
     wb = write["WRITE_SIZE"] * 1024
     fb = fetch["FETCH_SIZE"] * 1024 * 2
-    algo = BOARDS * ALGO_PER_BOARD
-    out = {"kernel": KERNEL.replace(" ", ""), "boards": BOARDS, "launches": n, "avg_kernel_us": avg_us,
+    algo = BOARDS * (PLIES * ALGO_PER_BOARD_PLY + ALGO_PER_BOARD_LAUNCH)
+    out = {"kernel": KERNEL.replace(" ", ""), "boards": BOARDS, "plies_per_launch": PLIES, "launches": n,
+           "avg_kernel_us": avg_us, "avg_us_per_ply": avg_us / PLIES,
            "write_bytes": wb, "fetch_bytes_corrected": fb, "traffic_bytes": wb + fb,
            "algorithmic_bytes": algo, "ratio": (wb + fb) / algo, "sq": dict(sorted(sq.items()))}
     json.dump(out, open(os.path.join(prof, rnd + "_pmc.json"), "w"), indent=1)
     waves = sq["SQ_WAVES"]
     wc = sq["SQ_WAVE_CYCLES"]
     md = []
-    md.append("# HBM traffic and wave-state counters of `%s`, %d boards per launch" % (out["kernel"], BOARDS))
+    md.append("# HBM traffic and wave-state counters of `%s`, %d boards x %d plies per launch" % (out["kernel"], BOARDS, PLIES))
     md.append("(rocprofv3 --pmc, one pass per counter group, tools/profile_round.sh + tools/summarize_pmc.py; %d launches averaged)\n" % n)
     md.append("| counter | avg per launch | bytes |\n|---|---|---|")
     md.append("| WRITE_SIZE | %.1f KB | %.2f MB (dwordx4 streaming stores: exact per the guide) |" % (write["WRITE_SIZE"], wb / 1e6))
-    md.append("| FETCH_SIZE | %.1f KB raw | x2 gfx950 correction = %.2f MB (record loads; narrow widths are uncalibrated: upper bound) |\n" % (fetch["FETCH_SIZE"], fb / 1e6))
-    md.append("Algorithmic bytes per launch = %d x (36,100 planes + 361 mask + 1,632 record write + 1,632 record read)" % BOARDS)
-    md.append("= %d x %d = %.2f MB.  Measured traffic = %.2f MB -> %.2fx algorithmic: no wasted re-reads, the kernel is a" % (BOARDS, ALGO_PER_BOARD, algo / 1e6, (wb + fb) / 1e6, out["ratio"]))
-    md.append("write stream.  Average kernel duration in the same trace: %.2f us.\n" % avg_us)
+    md.append("| FETCH_SIZE | %.1f KB raw | x2 gfx950 correction = %.2f MB (record loads, history table; narrow widths are uncalibrated: upper bound) |\n" % (fetch["FETCH_SIZE"], fb / 1e6))
+    md.append("Algorithmic bytes per launch = %d boards x (%d plies x (36,100 planes + 361 mask + 4 move) + 1,632 record read + 1,632 record write)" % (BOARDS, PLIES))
+    md.append("= %.2f MB.  Measured traffic = %.2f MB -> %.3fx algorithmic: no wasted re-reads, the kernel is a" % (algo / 1e6, (wb + fb) / 1e6, out["ratio"]))
+    md.append("write stream.  Average kernel duration in the same trace: %.2f us = %.2f us per ply.\n" % (avg_us, avg_us / PLIES))
     md.append("Wave-state counters (SQ, summed over the %d waves of a launch):\n" % waves)
     md.append("| counter | per launch | per wave | share of wave cycles |\n|---|---|---|---|")
     for k, label in (("SQ_WAVE_CYCLES", ""), ("SQ_ACTIVE_INST_ANY", " (issuing)"), ("SQ_WAIT_INST_ANY", " (issue stalls)"),
