@@ -73,9 +73,44 @@ __global__ __launch_bounds__(192) void p5_three_waves(float* out, int n) {
     if (lane == 26) o[pl * NP + 360] = v;
   }
 }
+// persistent variants: every board (one wave, or three) writes its 36,100-B block for T plies in a
+// row, as the generator kernel does.  lay 0: ring[t][b] (slot-major), lay 1: ring[b][t] (a board's
+// plies contiguous).
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void p_persist(float* out, int n, int T, int lay) {
+  int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int t = 0; t < T; ++t) {
+    float* o = out + (lay ? ((size_t)b * T + t) : ((size_t)t * n + b)) * FB;
+    for (int pl = w; pl < 25; pl += NWV) {
+      float v = (float)(pl + t);
+      uf4 val = {v, v + 1, v + 2, v + 3};
+      *(uf4*)(o + pl * NP + 4 * lane) = val;
+      if (lane < 26) *(uf4*)(o + pl * NP + 256 + 4 * lane) = val;
+      if (lane == 26) o[pl * NP + 360] = v;
+    }
+  }
+}
+static void run_persist(float* out, int n, int T, int reps) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int nwv = 1; nwv <= 3; nwv += 2)
+    for (int lay = 0; lay < 2; ++lay) {
+      for (int r = 0; r < reps + 1; ++r) {
+        if (r == 1) hipEventRecord(e0);
+        if (nwv == 1) hipLaunchKernelGGL(p_persist<1>, dim3(n), dim3(64), 0, 0, out, n, T, lay);
+        else hipLaunchKernelGGL(p_persist<3>, dim3(n), dim3(192), 0, 0, out, n, T, lay);
+      }
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+      printf("n=%d T=%d persistent %d wave(s)/board, %s  %8.3f us per ply  %7.1f GB/s\n", n, T, nwv,
+             lay ? "ring[b][t]" : "ring[t][b]", ms * 1e3 / T, (double)n * T * FB * 4 / (ms * 1e-3) / 1e9);
+    }
+}
 int main(int argc, char** argv) {
   int n = argc > 1 ? atoi(argv[1]) : 65536, reps = argc > 2 ? atoi(argv[2]) : 20;
-  float* out; hipMalloc(&out, (size_t)n * FB * 4 + 64);
+  const int T = argc > 3 ? atoi(argv[3]) : 0;   // > 0: the persistent variants only
+  float* out;
+  if (hipMalloc(&out, (size_t)n * (T > 0 ? T : 1) * FB * 4 + 64) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+  if (T > 0) { run_persist(out, n, T, reps); return 0; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   void (*ks[6])(float*, int) = {p0_kmajor, p1_planemajor, p2_planemajor_x4, p3_flat_aligned, p4_planemajor_x4_nt, p5_three_waves};
   const char* nm[6] = {"p0 k-major dword", "p1 plane-major dword", "p2 plane-major x4 (4B aligned)", "p3 flat aligned x4",
