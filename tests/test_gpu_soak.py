@@ -63,3 +63,39 @@ def test_parts_give_the_same_boards_as_one_launch_sequence():
     with pytest.raises(goenv.GoEnvError):
         env.ply_repeat_parts(1, 5, flags)               # more parts than boards
     env.close()
+
+
+@pytest.mark.parametrize("boards,plies,launches", [(1024, 64, 2), (4100, 8, 2)])
+def test_generator_rings_every_float(boards, plies, launches):
+    """The bench line's launch shape (1,024 boards x 64 plies per goenv_generate launch; 4,100
+    boards take the three-wave shape): every slot of the rings -- move, mask, all 9,025 floats --
+    against oracle boards that replay the moves."""
+    from elf_amd import goenv
+    goenv.load_library()
+    seed = 23
+    env = goenv.GoEnv(boards, seed=seed, max_ply=722)
+    dev = env.device
+    feat = torch.empty(plies, boards, 25, 19, 19, device=dev)
+    legal = torch.empty(plies, boards, 361, dtype=torch.uint8, device=dev)
+    moves = torch.empty(plies, boards, dtype=torch.int32, device=dev)
+    oracles = [OracleBoard() for _ in range(boards)]
+    bad = 0
+    for _ in range(launches):
+        feat.fill_(-3.0)
+        legal.fill_(9)
+        env.generate(plies, feat, legal, moves)
+        mv = moves.cpu().numpy()
+        for t in range(plies):
+            f = feat[t].cpu().numpy().reshape(boards, -1)
+            lg = legal[t].cpu().numpy()
+            for b, o in enumerate(oracles):
+                assert int(mv[t, b]) == o.policy_move(seed, b, 0), (t, b)
+                assert o.forward(int(mv[t, b]))[0]
+                if not np.array_equal(f[b], o.extract(0)) or not np.array_equal(lg[b], o.legal()):
+                    bad += 1
+    assert bad == 0, "%d of %d board-plies differ from the oracle" % (bad, boards * plies * launches)
+    st = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+    from common import assert_canon_equal
+    for b in range(0, boards, 37):
+        assert_canon_equal({k: v[b] for k, v in st.items()}, oracles[b].canonical(), "board %d" % b)
+    env.close()

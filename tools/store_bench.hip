@@ -105,12 +105,46 @@ static void run_persist(float* out, int n, int T, int reps) {
              lay ? "ring[b][t]" : "ring[t][b]", ms * 1e3 / T, (double)n * T * FB * 4 / (ms * 1e-3) / 1e9);
     }
 }
+// ceiling probes: plain aligned fills of the same byte count (no board structure at all)
+__global__ __launch_bounds__(256) void fill_gridstride(f4* out, size_t n4) {
+  f4 val = {1.f, 2.f, 3.f, 4.f};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) out[i] = val;
+}
+__global__ __launch_bounds__(256) void fill_chunked(f4* out, size_t n4) {   // each workgroup one contiguous chunk
+  f4 val = {1.f, 2.f, 3.f, 4.f};
+  const size_t per = (n4 + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = lo + per < n4 ? lo + per : n4;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) out[i] = val;
+}
+static void run_fills(float* out, int n, int reps) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const size_t n4 = (size_t)n * FB / 4;
+  const int grids[5] = {256, 1024, 2048, 8192, 65536};
+  for (int v = 0; v < 2; ++v)
+    for (int gi = 0; gi < 5; ++gi) {
+      for (int r = 0; r < reps + 1; ++r) {
+        if (r == 1) hipEventRecord(e0);
+        if (v == 0) hipLaunchKernelGGL(fill_gridstride, dim3(grids[gi]), dim3(256), 0, 0, (f4*)out, n4);
+        else hipLaunchKernelGGL(fill_chunked, dim3(grids[gi]), dim3(256), 0, 0, (f4*)out, n4);
+      }
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+      printf("fill %-11s %6d workgroups x 256  %9.3f us  %7.1f GB/s\n", v ? "chunked" : "grid-stride", grids[gi], ms * 1e3,
+             (double)n4 * 16 / (ms * 1e-3) / 1e9);
+    }
+  hipMemset(out, 0, n4 * 16); hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int r = 0; r < reps; ++r) hipMemsetAsync(out, 0, n4 * 16, 0);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+  printf("hipMemsetAsync %9.3f us  %7.1f GB/s\n", ms * 1e3, (double)n4 * 16 / (ms * 1e-3) / 1e9);
+}
 int main(int argc, char** argv) {
   int n = argc > 1 ? atoi(argv[1]) : 65536, reps = argc > 2 ? atoi(argv[2]) : 20;
   const int T = argc > 3 ? atoi(argv[3]) : 0;   // > 0: the persistent variants only
   float* out;
   if (hipMalloc(&out, (size_t)n * (T > 0 ? T : 1) * FB * 4 + 64) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
   if (T > 0) { run_persist(out, n, T, reps); return 0; }
+  if (T < 0) { run_fills(out, n, reps); return 0; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   void (*ks[6])(float*, int) = {p0_kmajor, p1_planemajor, p2_planemajor_x4, p3_flat_aligned, p4_planemajor_x4_nt, p5_three_waves};
   const char* nm[6] = {"p0 k-major dword", "p1 plane-major dword", "p2 plane-major x4 (4B aligned)", "p3 flat aligned x4",
