@@ -105,6 +105,46 @@ static void run_persist(float* out, int n, int T, int reps) {
              lay ? "ring[b][t]" : "ring[t][b]", ms * 1e3 / T, (double)n * T * FB * 4 / (ms * 1e-3) / 1e9);
     }
 }
+// persistent, one wave per board, with at most VM plane stores of the wave in flight (does a
+// narrower window of outstanding writes help DRAM locality, as the plain fills suggest?)
+template <int VM>
+__global__ __launch_bounds__(64) void p_persist_throttled(float* out, int n, int T) {
+  int b = blockIdx.x, lane = threadIdx.x;
+  for (int t = 0; t < T; ++t) {
+    float* o = out + ((size_t)t * n + b) * FB;
+    for (int pl = 0; pl < 25; ++pl) {
+      float v = (float)(pl + t);
+      uf4 val = {v, v + 1, v + 2, v + 3};
+      *(uf4*)(o + pl * NP + 4 * lane) = val;
+      if (lane < 26) *(uf4*)(o + pl * NP + 256 + 4 * lane) = val;
+      if (lane == 26) o[pl * NP + 360] = v;
+      if (VM == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (VM == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      if (VM == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      if (VM == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    }
+  }
+}
+static void run_throttled(float* out, int n, int T, int reps) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int vms[5] = {0, 3, 6, 12, 63};
+  for (int vi = 0; vi < 5; ++vi) {
+    for (int r = 0; r < reps + 1; ++r) {
+      if (r == 1) hipEventRecord(e0);
+      switch (vms[vi]) {
+        case 0: hipLaunchKernelGGL(p_persist_throttled<0>, dim3(n), dim3(64), 0, 0, out, n, T); break;
+        case 3: hipLaunchKernelGGL(p_persist_throttled<3>, dim3(n), dim3(64), 0, 0, out, n, T); break;
+        case 6: hipLaunchKernelGGL(p_persist_throttled<6>, dim3(n), dim3(64), 0, 0, out, n, T); break;
+        case 12: hipLaunchKernelGGL(p_persist_throttled<12>, dim3(n), dim3(64), 0, 0, out, n, T); break;
+        default: hipLaunchKernelGGL(p_persist_throttled<63>, dim3(n), dim3(64), 0, 0, out, n, T); break;
+      }
+    }
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("n=%d T=%d persistent 1 wave/board, at most %2d store groups in flight  %8.3f us per ply  %7.1f GB/s\n", n, T,
+           vms[vi], ms * 1e3 / T, (double)n * T * FB * 4 / (ms * 1e-3) / 1e9);
+  }
+}
 // ceiling probes: plain aligned fills of the same byte count (no board structure at all)
 __global__ __launch_bounds__(256) void fill_gridstride(f4* out, size_t n4) {
   f4 val = {1.f, 2.f, 3.f, 4.f};
@@ -143,7 +183,7 @@ int main(int argc, char** argv) {
   const int T = argc > 3 ? atoi(argv[3]) : 0;   // > 0: the persistent variants only
   float* out;
   if (hipMalloc(&out, (size_t)n * (T > 0 ? T : 1) * FB * 4 + 64) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
-  if (T > 0) { run_persist(out, n, T, reps); return 0; }
+  if (T > 0) { run_persist(out, n, T, reps); run_throttled(out, n, T, reps); return 0; }
   if (T < 0) { run_fills(out, n, reps); return 0; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   void (*ks[6])(float*, int) = {p0_kmajor, p1_planemajor, p2_planemajor_x4, p3_flat_aligned, p4_planemajor_x4_nt, p5_three_waves};
