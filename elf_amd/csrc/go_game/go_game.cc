@@ -31,6 +31,7 @@
 #include "offline_loader.h"
 #include "sgf_record.h"
 #include "tree_search.h"
+#include "worker_pool.h"
 
 namespace py = pybind11;
 using namespace gogame;
@@ -490,6 +491,7 @@ class GameContext {
   std::vector<int> finished_;   // games whose search has spent its rollouts
   std::mt19937 pick_rng_;
   DevBuf ts_src_, ts_dst_, ts_act_, ts_status_, ts_topa_, ts_topp_, ts_v_;
+  WorkerPool pool_;             // host threads for per-game work between two device batches
 
   static uint64_t clock_seed() {
     using namespace std::chrono;
@@ -545,6 +547,10 @@ class GameContext {
   void pump(int g) {
     std::vector<LeafRequest> rq;
     searches_[g]->advance(&rq);
+    queue_leaves(g, rq);
+  }
+
+  void queue_leaves(int g, const std::vector<LeafRequest>& rq) {
     const int e = group_of("actor");
     for (const LeafRequest& r : rq) {
       games_[g].requests[r.thread] = r;
@@ -856,15 +862,26 @@ class GameContext {
     if (itv->second.device) env_->d2h(value.data(), itv->second.p, (size_t)n * 4);
     env_->sync();
     if (!itv->second.device) std::memcpy(value.data(), itv->second.p, (size_t)n * 4);
+    // The trees of different games share nothing: the games of the batch are expanded and run on
+    // to their next leaves in parallel on the host pool (rows of one game stay in row order), then
+    // their leaves are queued in game order, so the batches are the same for any number of threads.
     std::vector<int> touched;
-    for (int r = 0; r < n; ++r) {
-      const int g = c.games[r] / tick_, t = c.games[r] % tick_ - 1;
-      searches_[g]->expand(t, &top_a[(size_t)r * K], &top_p[(size_t)r * K], K, value[r]);
-      if (touched.empty() || touched.back() != g) touched.push_back(g);
-    }
+    for (int r = 0; r < n; ++r) touched.push_back(c.games[r] / tick_);
     std::sort(touched.begin(), touched.end());
     touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
-    for (int g : touched) pump(g);
+    std::vector<std::vector<int>> rows_of(touched.size());
+    for (int r = 0; r < n; ++r) {
+      const int g = c.games[r] / tick_;
+      rows_of[std::lower_bound(touched.begin(), touched.end(), g) - touched.begin()].push_back(r);
+    }
+    std::vector<std::vector<LeafRequest>> next(touched.size());
+    pool_.run((int)touched.size(), [&](int i) {
+      TreeSearch& ts = *searches_[touched[i]];
+      for (int r : rows_of[i])
+        ts.expand(c.games[r] % tick_ - 1, &top_a[(size_t)r * K], &top_p[(size_t)r * K], K, value[r]);
+      ts.advance(&next[i]);
+    });
+    for (size_t i = 0; i < touched.size(); ++i) queue_leaves(touched[i], next[i]);
   }
 
   // offline: OfflineLoader::handle_response -> next() for every sample of the batch

@@ -1,0 +1,115 @@
+// worker_pool.h -- a small fork/join pool for the host side of the GameContext: independent
+// per-game work (the trees of a tree-search batch) is spread over a few host threads between two
+// device batches.  The calling thread takes part; run() returns when every index has been done.
+// No Python is touched inside (Wait / Steps run with the GIL released).
+#pragma once
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <exception>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace gogame {
+
+class WorkerPool {
+ public:
+  // threads = 0: GOENV_HOST_THREADS if set, else min(8, hardware threads); 1 = run inline
+  explicit WorkerPool(int threads = 0) {
+    if (threads <= 0) {
+      if (const char* e = std::getenv("GOENV_HOST_THREADS")) threads = std::atoi(e);
+      if (threads <= 0) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        threads = (int)(hw ? (hw < 8u ? hw : 8u) : 1u);
+      }
+    }
+    if (threads > 64) threads = 64;
+    for (int i = 1; i < threads; ++i) workers_.emplace_back([this] { loop(); });
+  }
+
+  ~WorkerPool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+      generation_ += 1;
+    }
+    wake_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+
+  WorkerPool(const WorkerPool&) = delete;
+  WorkerPool& operator=(const WorkerPool&) = delete;
+
+  int threads() const { return (int)workers_.size() + 1; }
+
+  // fn(i) for every i in [0, count); the first exception thrown by any fn(i) is rethrown here
+  void run(int count, const std::function<void(int)>& fn) {
+    if (count <= 0) return;
+    if (workers_.empty() || count == 1) {
+      for (int i = 0; i < count; ++i) fn(i);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn;
+      count_ = count;
+      next_.store(0);
+      active_ = (int)workers_.size();
+      error_ = nullptr;
+      generation_ += 1;
+    }
+    wake_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this] { return active_ == 0; });
+    fn_ = nullptr;
+    if (error_) std::rethrow_exception(error_);
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= count_) return;
+      try {
+        (*fn_)(i);
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(m_);
+        if (!error_) error_ = std::current_exception();
+      }
+    }
+  }
+
+  void loop() {
+    unsigned long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        wake_.wait(lk, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (stop_) return;
+      }
+      work();
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        active_ -= 1;
+      }
+      done_.notify_one();
+    }
+  }
+
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable wake_, done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int count_ = 0, active_ = 0;
+  unsigned long generation_ = 0;
+  bool stop_ = false;
+  std::exception_ptr error_;
+};
+
+}  // namespace gogame

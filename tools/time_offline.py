@@ -98,7 +98,11 @@ def run_reference_child(args):
         v = np.zeros(info.sz, dtype=NP_TYPES[info.type])
         return v, v.ctypes.data, v.size * v.dtype.itemsize
 
-    keep = drive(go, args.games, args.batches, host_buffer, lambda: None)
+    try:
+        keep = drive(go, args.games, args.batches, host_buffer, lambda: None)
+    except BaseException as e:      # the reference's teardown blocks: never fall out of this function
+        print(json.dumps({"error": repr(e)}), flush=True)
+        os._exit(1)
     print(json.dumps({"samples": keep[2], "seconds": keep[3], "samples_per_s": keep[2] / keep[3],
                       "threads": args.games, "cpus": len(os.sched_getaffinity(0))}), flush=True)
     os._exit(0)
