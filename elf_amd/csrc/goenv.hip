@@ -55,7 +55,8 @@ struct PlyParams {
     unsigned long long t_ = __builtin_amdgcn_s_memtime();                          \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                            \
     __builtin_amdgcn_sched_barrier(0);                                             \
-    if (P.stamps && threadIdx.x == 0) P.stamps[(size_t)blockIdx.x * 16 + (i)] = t_; \
+    if (P.stamps && (threadIdx.x & 63) == 0 && threadIdx.x < 128)                  \
+      P.stamps[(size_t)blockIdx.x * 32 + (threadIdx.x >> 6) * 16 + (i)] = t_;      \
   } while (0)
 #else
 #define STAMP(i) do { } while (0)
@@ -618,20 +619,25 @@ __global__ __launch_bounds__(64 * NW) void k_generate(PlyParams P, int n_plies, 
   for (int k = 0; k < K; ++k) hv_none[k] = 0.f;
   for (int t = 0; t < n_plies; ++t) {  // host-supplied bound, the same for every wave
     if (NW > 1) WSYNC();  // the previous ply's plane stores have taken their LDS operands
+    STAMP(8);
     if (s.done) {
       if (!s.counted) account_game(P.stats, g.tid, s, tromp_taylor(L, g, lab), P.komi);
       restart_in_place(L, g, lab, lastp, s, m, o);
     }
     const int a = ply_body<NW, true>(L, g, lab, lastp, s, m, o, P, b, 0ll);
+    STAMP(9);
     gather_masks(L, g, o, m);
+    STAMP(10);
     const size_t row = (size_t)t * P.n + b;
     if (actions_ring && g.tid == 0) actions_ring[row] = a;
     if (P.legal) write_legal(g, o, P.legal + row * NPTS);
+    STAMP(11);
     if (P.feat) {
       const int aug = P.aug ? (P.aug[b] & 7) : 0;
       write_features<NW, true, false>(L, g, lab, lastp, s, aug, P.lut, P.feat + row * GOENV_FEAT_FLOATS, hv_none, -1,
-                                      P.lut1);
+                                      P.lut1, P.stamps);
     }
+    STAMP(12);
   }
   store_board(rec, g, lab, lastp, o, s);
 }
@@ -1092,8 +1098,20 @@ int goenv_ply_repeat_parts(goenv_ctx* c, int n_steps, int n_parts, uint32_t flag
 }
 
 #ifdef GOENV_STAMPS
+// Diagnostic build only: stamps [n][2 waves][16] of the LAST ply of a generator launch (slots 8..12: loop
+// top, rules + masks done, masks gathered, legal written, planes issued; 2, 3 inside the rules).
+extern "C" int goenv_diag_generate(goenv_ctx* c, int n_plies, float* feat_ring, uint8_t* legal_ring,
+                                   unsigned long long* stamps, void* stream) {
+  PlyParams P = make_params(c, GOENV_F_RANDOM_POLICY | GOENV_F_AUTO_RESTART, nullptr, nullptr, feat_ring, legal_ring,
+                            nullptr, nullptr);
+  P.stamps = stamps;
+  const int nw = c->nw ? c->nw : (c->n <= 4096 ? 2 : 3);
+  GO_LAUNCH(nw, k_generate, c->n, S(stream), P, n_plies, (int32_t*)nullptr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 // Diagnostic build only (libgoenv_diag.so, tools/stamps.py): per-board s_memtime stamps
-// [n][16] of one fused random ply.  Never part of libgoenv.so.
+// [n][2 waves][16] of one fused random ply.  Never part of libgoenv.so.
 extern "C" int goenv_diag_ply(goenv_ctx* c, uint32_t flags, float* feat_out, uint8_t* legal_out,
                               unsigned long long* stamps, void* stream) {
   PlyParams P = make_params(c, flags | GOENV_F_RANDOM_POLICY, nullptr, nullptr, feat_out, legal_out, nullptr, nullptr);

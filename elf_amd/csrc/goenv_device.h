@@ -789,7 +789,21 @@ template <int NW, bool ZEROS, bool WT>
 __device__ __forceinline__ void write_features(BoardLds<NW>& L, const Geo<NW>& g, const uint32_t lab[],
                                                const uint32_t lastp[], const Scalars& s, int aug,
                                                const float* __restrict__ lut, float* __restrict__ out,
-                                               const float hv_pre[], int pre_ply, float lut1) {
+                                               const float hv_pre[], int pre_ply, float lut1,
+                                               unsigned long long* dbg_stamps = nullptr) {
+#ifdef GOENV_STAMPS
+#define FSTAMP(i)                                                                                     \
+  do {                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    unsigned long long t_ = __builtin_amdgcn_s_memtime();                                             \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if (dbg_stamps && (threadIdx.x & 63) == 0 && threadIdx.x < 128)                                   \
+      dbg_stamps[(size_t)blockIdx.x * 32 + (threadIdx.x >> 6) * 16 + (i)] = t_;                       \
+  } while (0)
+#else
+#define FSTAMP(i) do { (void)dbg_stamps; } while (0)
+#endif
   constexpr int K = Geo<NW>::K;
   const int lane = g.lane;
   float hv[K];
@@ -825,7 +839,9 @@ __device__ __forceinline__ void write_features(BoardLds<NW>& L, const Geo<NW>& g
       hist[q] = hv[k];
     }
   }
+  FSTAMP(13);
   WSYNC();
+  FSTAMP(14);
   if (NW > 1) {
     GO_UNROLL
     for (int j = 0; j < NWORDS; ++j) { wb[j] = uni64(L.xcol[j]); ww[j] = uni64(L.xcol[NWORDS + j]); }
@@ -861,6 +877,9 @@ __device__ __forceinline__ void write_features(BoardLds<NW>& L, const Geo<NW>& g
   // the 12 planes that need no distance, as 4 store groups dealt round-robin to the storing
   // waves (all waves but wave 0 when NW > 1)
   constexpr int NS = NW > 1 ? NW - 1 : 1;                 // storing waves in this phase
+  // two waves per board: the one storing wave has 12 planes to compute and store while wave 0 runs the
+  // distance transform, which takes half as long -- wave 0 takes the 11 constant planes after it
+  constexpr bool ZEROS_WAVE0 = NW == 2;
   const int sw = NW > 1 ? g.wave - 1 : 0;                 // this wave's index among them (-1: wave 0)
   if (NW == 1 || g.wave > 0) {
     GO_UNROLL
@@ -889,9 +908,9 @@ __device__ __forceinline__ void write_features(BoardLds<NW>& L, const Geo<NW>& g
       GO_PLANE(9, col == 0 ? 1.f : 0.f);
       GO_PLANE(10, mine ? hh : 0.f);
       GO_PLANE(11, theirs ? hh : 0.f);
-      if (ZEROS) zero_range<WT>(out + 12 * NPTS, 2 * NPTS, lane);   // BORDER, POSITION_MARK: never filled
+      if (ZEROS && !ZEROS_WAVE0) zero_range<WT>(out + 12 * NPTS, 2 * NPTS, lane);   // BORDER, POSITION_MARK: never filled
     }
-    if (ZEROS) {                                                // planes 16..24: never filled
+    if (ZEROS && !ZEROS_WAVE0) {                                // planes 16..24: never filled
       if (4 % NS == sw) zero_range<WT>(out + 16 * NPTS, 4 * NPTS, lane);
       if (5 % NS == sw) zero_range<WT>(out + 20 * NPTS, 5 * NPTS, lane);
     }
@@ -899,7 +918,13 @@ __device__ __forceinline__ void write_features(BoardLds<NW>& L, const Geo<NW>& g
 #ifndef GOENV_ABLATE_DIST
   if (g.wave == 0) distance_lines(L, lane, wb, ww, aug);
 #endif
+  if (ZEROS && ZEROS_WAVE0 && g.wave == 0) {
+    zero_range<WT>(out + 12 * NPTS, 2 * NPTS, lane);
+    zero_range<WT>(out + 16 * NPTS, 9 * NPTS, lane);
+  }
+  FSTAMP(15);
   WSYNC();
+  FSTAMP(7);
   // planes 14 / 15 straight from the distance tables (already in output order)
   if (g.wave == 0 || (NW > 1 && g.wave == 1)) {
     const bool second = NW > 1 && g.wave == 1;                       // wave 1 takes plane 15
@@ -914,6 +939,7 @@ __device__ __forceinline__ void write_features(BoardLds<NW>& L, const Geo<NW>& g
     }
   }
 #undef GO_PLANE
+#undef FSTAMP
 }
 
 template <int NW>

@@ -18,7 +18,7 @@ lib.goenv_diag_ply.restype = C.c_int
 lib.goenv_diag_ply.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 env = goenv.GoEnv(B, seed=1)
 feat, legal = env.new(torch.float32, 25, 19, 19), env.new(torch.uint8, 361)
-stamps = torch.zeros((B, 16), dtype=torch.int64, device=env.device)
+stamps = torch.zeros((B, 32), dtype=torch.int64, device=env.device)   # [board][wave 0 / 1][16]
 for _ in range(warm):
     env.ply(goenv.F_RANDOM_POLICY | goenv.F_AUTO_RESTART, feat_out=feat, legal_out=legal)
 names = {1: "load_board", 2: "pick_move", 3: "apply+rebuild", 4: "move_masks", 5: "store_state", 6: "legal_out", 7: "features"}
