@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <stdint.h>
 #define NP 361
 #define FB 9025
 
@@ -178,11 +179,197 @@ static void run_fills(float* out, int n, int reps) {
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
   printf("hipMemsetAsync %9.3f us  %7.1f GB/s\n", ms * 1e3, (double)n4 * 16 / (ms * 1e-3) / 1e9);
 }
+
+// ---- two-stage probes: a rules kernel would leave one packed dword per point (1,472 B per board-ply) and a
+// separate "expander" would write the 36,100-B sample.  How fast can such an expander write, as a function of
+// how wide the chip-wide write front is?
+// fill_front: G workgroups in teams of g; team i writes boards i, i+G/g, ...; member m of a team writes the m-th
+// slice of the board.  g = 1: every workgroup whole boards (front = G boards wide).
+__global__ __launch_bounds__(256) void fill_front(float* out, int nbp, int g) {
+  const int team = blockIdx.x / g, mem = blockIdx.x % g, nteams = gridDim.x / g;
+  const int Q = (((FB + g - 1) / g) + 3) & ~3;
+  const int lo = mem * Q, hi = lo + Q < FB ? lo + Q : FB;
+  for (int bp = team; bp < nbp; bp += nteams) {
+    float* o = out + (size_t)bp * FB;
+    const int body = lo + ((hi - lo) & ~3);
+    for (int i = lo + 4 * (int)threadIdx.x; i < body; i += 1024) { uf4 v = {1.f, 2.f, 3.f, (float)bp}; *(uf4*)(o + i) = v; }
+    if ((int)threadIdx.x < hi - body) o[body + threadIdx.x] = 5.f;
+  }
+}
+#define CW 368   // dwords per packed board-ply: 361 points + header
+__global__ void init_comp(uint32_t* comp, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)(i * 2654435761u); h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    const int q = (int)(i % CW);
+    uint32_t col = h % 3, cls = col ? 1 + (h >> 4) % 3 : 0;
+    comp[i] = q < NP ? (col | cls << 2 | ((h >> 8) % 97 == 0) << 4 | ((h >> 10) % 300) << 5 | ((h >> 20) % 37) << 16 | ((h >> 26) % 37) << 24)
+                     : (1 + ((i / CW) & 1)) | 3u << 2;
+  }
+}
+__device__ __forceinline__ float plane_val(int pl, uint32_t W, uint32_t our, uint32_t has, const float* lut) {
+  const uint32_t col = W & 3u, cls = (W >> 2) & 3u, opp = 3u - our;
+  const bool mine = col == our, theirs = col == opp;
+  switch (pl) {
+    case 0: return (mine && cls == 1) ? 1.f : 0.f;
+    case 1: return (mine && cls == 2) ? 1.f : 0.f;
+    case 2: return (mine && cls != 1 && cls != 2) ? 1.f : 0.f;
+    case 3: return (theirs && cls == 1) ? 1.f : 0.f;
+    case 4: return (theirs && cls == 2) ? 1.f : 0.f;
+    case 5: return (theirs && cls != 1 && cls != 2) ? 1.f : 0.f;
+    case 6: return (W & 16u) ? 1.f : 0.f;
+    case 7: return mine ? 1.f : 0.f;
+    case 8: return theirs ? 1.f : 0.f;
+    case 9: return col == 0 ? 1.f : 0.f;
+    case 10: return mine ? lut[(W >> 5) & 0x7ffu] : 0.f;
+    case 11: return theirs ? lut[(W >> 5) & 0x7ffu] : 0.f;
+    case 14: return ((has >> (our - 1)) & 1u) ? (float)((W >> (our == 1 ? 16 : 24)) & 0xffu) : 10000.f;
+    case 15: return ((has >> (opp - 1)) & 1u) ? (float)((W >> (opp == 1 ? 16 : 24)) & 0xffu) : 10000.f;
+    default: return 0.f;
+  }
+}
+// expand_board: one workgroup (4 waves) per board-ply, boards dealt round-robin (front = gridDim boards wide).
+// Thread t owns points 4t..4t+3 (t < 90) and thread 90 points 357..360; wave w stores planes w, w+4, ...
+// restricted to its own points: plane-major over the workgroup, so two wave-stores per plane as in the product.
+__global__ __launch_bounds__(256) void expand_board(const uint32_t* __restrict__ comp, const float* __restrict__ lut,
+                                                    float* __restrict__ out, int nbp) {
+  __shared__ float slut[2048];
+  __shared__ uint32_t rec[2][CW];
+  for (int i = threadIdx.x; i < 2048; i += 256) slut[i] = lut[i];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int qa = 4 * lane, qb = lane < 26 ? 256 + 4 * lane : NP - 4;
+  const bool act_b = lane <= 26;
+  int bp = blockIdx.x, cur = 0;
+  uint32_t pre0 = 0, pre1 = 0;
+  if (bp < nbp) { pre0 = comp[(size_t)bp * CW + threadIdx.x]; if (threadIdx.x < CW - 256) pre1 = comp[(size_t)bp * CW + 256 + threadIdx.x]; }
+  for (; bp < nbp; bp += gridDim.x, cur ^= 1) {
+    rec[cur][threadIdx.x] = pre0; if (threadIdx.x < CW - 256) rec[cur][256 + threadIdx.x] = pre1;
+    __syncthreads();
+    const int nx = bp + gridDim.x;
+    if (nx < nbp) { pre0 = comp[(size_t)nx * CW + threadIdx.x]; if (threadIdx.x < CW - 256) pre1 = comp[(size_t)nx * CW + 256 + threadIdx.x]; }
+    const uint32_t hdr = rec[cur][NP], our = hdr & 3u, has = hdr >> 2;
+    uint32_t d[8];
+    for (int i = 0; i < 4; ++i) { d[i] = rec[cur][qa + i]; d[4 + i] = rec[cur][qb + i]; }
+    float* o = out + (size_t)bp * FB;
+#pragma unroll
+    for (int pl = 0; pl < 25; ++pl) {
+      if ((pl & 3) != w) continue;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = plane_val(pl, d[i], our, has, slut);
+      uf4 va = {v[0], v[1], v[2], v[3]}, vb = {v[4], v[5], v[6], v[7]};
+      *(uf4*)(o + pl * NP + qa) = va;
+      if (act_b) *(uf4*)(o + pl * NP + qb) = vb;
+    }
+  }
+}
+// expand_flat: XCD-aware narrow front.  Workgroup w runs on XCD w%8 (round-robin dispatch); XCD x owns the
+// board-plies bp = 8k + x and its gridDim/8 workgroups walk them as ONE flat float stream, 4 floats per thread.
+__global__ __launch_bounds__(256) void expand_flat(const uint32_t* __restrict__ comp, const float* __restrict__ lut,
+                                                   float* __restrict__ out, int nbp, int compute) {
+  __shared__ float slut[2048];
+  for (int i = threadIdx.x; i < 2048; i += 256) slut[i] = lut[i];
+  __syncthreads();
+  const int x = blockIdx.x & 7, s = blockIdx.x >> 3, S = gridDim.x >> 3;
+  const long long nk = (nbp - x + 7) >> 3, total = nk * FB;
+  for (long long base = ((long long)s * 256 + threadIdx.x) * 4; base < total; base += (long long)S * 1024) {
+    int k = (int)(base / FB), r = (int)(base - (long long)k * FB);
+    float v[4];
+    size_t bp = (size_t)8 * k + x;
+    float* o = out + bp * FB + r;
+    if (!compute) { uf4 vv = {1.f, 2.f, 3.f, (float)k}; if (r <= FB - 4) *(uf4*)o = vv; else for (int j = 0; j < FB - r; ++j) o[j] = 1.f; continue; }
+    int pl = r / NP, q = r - pl * NP;
+    const uint32_t* c = comp + bp * CW;
+    const uint32_t hdr = c[NP], our = hdr & 3u, has = hdr >> 2;
+    const int nfl = r <= FB - 4 ? 4 : FB - r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool zero = pl == 12 || pl == 13 || pl >= 16;
+      v[j] = zero ? 0.f : plane_val(pl, c[q], our, has, slut);
+      if (++q == NP) { q = 0; ++pl; }
+    }
+    if (nfl == 4) { uf4 vv = {v[0], v[1], v[2], v[3]}; *(uf4*)o = vv; }
+    else {
+      for (int j = 0; j < nfl; ++j) o[j] = v[j];
+      // the floats past this board's end belong to the XCD's next board (8 boards on in memory)
+      if ((long long)(k + 1) < nk) {
+        float* o2 = out + (bp + 8) * FB; const uint32_t* c2 = comp + (bp + 8) * CW;
+        const uint32_t h2 = c2[NP];
+        for (int j = nfl; j < 4; ++j) o2[j - nfl] = plane_val(0, c2[j - nfl], h2 & 3u, h2 >> 2, slut);
+      }
+    }
+  }
+}
+
+// board <-> workgroup permutations of the persistent one-wave-per-board store (ring[t][b]): does it matter
+// which XCD writes which board?  map 0: board = workgroup; 1: XCD x (= workgroup % 8) owns the contiguous
+// boards [x n/8, (x+1) n/8); 2: CU-contiguous (workgroups that share a CU own neighbouring boards, assuming
+// round-robin over 8 XCDs x 32 CUs); 3: a fixed odd-multiplier shuffle (no locality at all).
+__global__ __launch_bounds__(64) void p_persist_map(float* out, int n, int T, int map, int nper) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  int b = w;
+  if (map == 1) b = (w & 7) * (n >> 3) + (w >> 3);
+  else if (map == 2) { const int cu = w & 255, k = w >> 8; b = cu * (n >> 8) + k; }
+  else if (map == 3) b = (int)(((unsigned)w * 40503u) % (unsigned)n);
+  for (int t = 0; t < T; ++t) {
+    float* o = out + ((size_t)t * n + b) * FB;
+    for (int pl = 0; pl < 25; ++pl) {
+      float v = (float)(pl + t);
+      uf4 val = {v, v + 1, v + 2, v + 3};
+      *(uf4*)(o + pl * NP + 4 * lane) = val;
+      if (lane < 26) *(uf4*)(o + pl * NP + 256 + 4 * lane) = val;
+      if (lane == 26) o[pl * NP + 360] = v;
+      if (nper && (pl % nper) == nper - 1) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+}
+static void run_map(float* out, int n, int T, int reps) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int map = 0; map < 4; ++map) {
+    for (int r = 0; r < reps + 1; ++r) { if (r == 1) hipEventRecord(e0); hipLaunchKernelGGL(p_persist_map, dim3(n), dim3(64), 0, 0, out, n, T, map, 0); }
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("n=%d T=%d persistent 1 wave/board ring[t][b], board map %d  %8.3f us per ply  %7.1f GB/s\n", n, T, map,
+           ms * 1e3 / T, (double)n * T * FB * 4 / (ms * 1e-3) / 1e9);
+  }
+}
+static void run_front(float* out, int n, int T, int reps) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int nbp = n * T;
+  uint32_t* comp; float* lut;
+  hipMalloc(&comp, (size_t)(nbp + 16) * CW * 4); hipMalloc(&lut, 2048 * 4);
+  hipLaunchKernelGGL(init_comp, dim3(1024), dim3(256), 0, 0, comp, (size_t)(nbp + 16) * CW);
+  hipMemset(lut, 0, 2048 * 4); hipDeviceSynchronize();
+  const double bytes = (double)nbp * FB * 4;
+  float ms;
+  const int gs[6] = {1, 2, 4, 8, 32, 256};
+  const int Gs[4] = {256, 512, 1024, 2048};
+  for (int Gi = 0; Gi < 4; ++Gi)
+    for (int gi = 0; gi < 6; ++gi) {
+      if (Gi > 0 && gi > 1) continue;
+      for (int r = 0; r < reps + 1; ++r) { if (r == 1) hipEventRecord(e0); hipLaunchKernelGGL(fill_front, dim3(Gs[Gi]), dim3(256), 0, 0, out, nbp, gs[gi]); }
+      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+      printf("fill_front   %5d workgroups, teams of %3d  %9.3f us  %7.1f GB/s\n", Gs[Gi], gs[gi], ms * 1e3, bytes / (ms * 1e-3) / 1e9);
+    }
+  for (int Gi = 0; Gi < 4; ++Gi) {
+    for (int r = 0; r < reps + 1; ++r) { if (r == 1) hipEventRecord(e0); hipLaunchKernelGGL(expand_board, dim3(Gs[Gi]), dim3(256), 0, 0, comp, lut, out, nbp); }
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("expand_board %5d workgroups  %9.3f us  %7.1f GB/s\n", Gs[Gi], ms * 1e3, bytes / (ms * 1e-3) / 1e9);
+  }
+  for (int c = 0; c < 2; ++c)
+    for (int Gi = 0; Gi < 4; ++Gi) {
+      for (int r = 0; r < reps + 1; ++r) { if (r == 1) hipEventRecord(e0); hipLaunchKernelGGL(expand_flat, dim3(Gs[Gi]), dim3(256), 0, 0, comp, lut, out, nbp, c); }
+      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+      printf("expand_flat  %5d workgroups, %s  %9.3f us  %7.1f GB/s\n", Gs[Gi], c ? "expanding" : "fill only", ms * 1e3, bytes / (ms * 1e-3) / 1e9);
+    }
+}
 int main(int argc, char** argv) {
   int n = argc > 1 ? atoi(argv[1]) : 65536, reps = argc > 2 ? atoi(argv[2]) : 20;
   const int T = argc > 3 ? atoi(argv[3]) : 0;   // > 0: the persistent variants only
+  const int front = argc > 4 ? atoi(argv[4]) : 0; // 1: the two-stage (expander) probes over n*T board-plies
   float* out;
   if (hipMalloc(&out, (size_t)n * (T > 0 ? T : 1) * FB * 4 + 64) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+  if (front == 2) { run_map(out, n, T, reps); return 0; }
+  if (front) { run_front(out, n, T, reps); return 0; }
   if (T > 0) { run_persist(out, n, T, reps); run_throttled(out, n, T, reps); return 0; }
   if (T < 0) { run_fills(out, n, reps); return 0; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Times goenv_generate (persistent multi-ply launch writing planes + masks per ply into ring
 buffers) for every launch shape (waves per board) and both plane-store policies
-(GOENV_ZERO_FIRST: 0 = plain stores, 2 = write-through).
+(GOENV_ZERO_FIRST: 0 = plain stores, 2 = write-through; TG_STORES=0 times the plain ones only).
+GOENV_XCD_MAP=0 in the environment turns the XCD-contiguous dealing of rows off.
 Usage: tools/time_generate.py [boards [plies_per_launch]]"""
 import os
 import sys
@@ -18,7 +19,7 @@ print("%6s %3s %5s %12s %10s %9s" % ("boards", "nw", "store", "us per ply", "Mmo
 feat = torch.zeros(T, B, 25, 19, 19, device="cuda")
 legal = torch.zeros(T, B, 361, dtype=torch.uint8, device="cuda")
 moves = torch.zeros(T, B, dtype=torch.int32, device="cuda")
-for zf in ("0", "2"):
+for zf in os.environ.get("TG_STORES", "0,2").split(","):
     os.environ["GOENV_ZERO_FIRST"] = zf          # read by goenv_create
     for nw in (1, 2, 3, 6):
         env = goenv.GoEnv(B, seed=1, max_ply=722)
