@@ -332,6 +332,163 @@ static void run_map(float* out, int n, int T, int reps) {
            ms * 1e3 / T, (double)n * T * FB * 4 / (ms * 1e-3) / 1e9);
   }
 }
+
+// two waves per board (as the generator at <= 4,096 boards), XCD-contiguous boards, one barrier per ply:
+// how should the 25 planes be split between the waves?  split 0: wave 0 planes 0..11, wave 1 planes 12..24;
+// 1: even / odd planes; 2: the generator's (wave 1: 0..11, wave 0: 12, 13, 16..24, then 14 | 15 after a
+// barrier); 3: wave 0 stores everything, wave 1 idles; 4: as 0 without the barrier.
+__global__ __launch_bounds__(128) void p_persist2(float* out, int n, int T, int split) {
+  const int w0 = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = (w0 & 7) * (n >> 3) + (w0 >> 3);
+  for (int t = 0; t < T; ++t) {
+    float* o = out + ((size_t)t * n + b) * FB;
+#define PL(pl) do { float v = (float)((pl) + t); uf4 val = {v, v + 1, v + 2, v + 3}; *(uf4*)(o + (pl) * NP + 4 * lane) = val; \
+    if (lane < 26) *(uf4*)(o + (pl) * NP + 256 + 4 * lane) = val; if (lane == 26) o[(pl) * NP + 360] = v; } while (0)
+    if (split == 0 || split == 4) { if (w == 0) for (int pl = 0; pl < 12; ++pl) PL(pl); else for (int pl = 12; pl < 25; ++pl) PL(pl); }
+    else if (split == 1) { for (int pl = w; pl < 25; pl += 2) PL(pl); }
+    else if (split == 2) {
+      if (w == 1) for (int pl = 0; pl < 12; ++pl) PL(pl);
+      else { PL(12); PL(13); for (int pl = 16; pl < 25; ++pl) PL(pl); }
+      __syncthreads();
+      if (w == 0) PL(14); else PL(15);
+    } else if (split == 3) { if (w == 0) for (int pl = 0; pl < 25; ++pl) PL(pl); }
+#undef PL
+    if (split != 4) __syncthreads();
+  }
+}
+static void run_split(float* out, int n, int T, int reps) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int sp = 0; sp < 5; ++sp) {
+    for (int r = 0; r < reps + 1; ++r) { if (r == 1) hipEventRecord(e0); hipLaunchKernelGGL(p_persist2, dim3(n), dim3(128), 0, 0, out, n, T, sp); }
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("n=%d T=%d persistent 2 waves/board ring[t][b], XCD-contiguous, plane split %d  %8.3f us per ply  %7.1f GB/s\n", n, T, sp,
+           ms * 1e3 / T, (double)n * T * FB * 4 / (ms * 1e-3) / 1e9);
+  }
+}
+
+// how many concurrent sequential streams does the memory side like?  n boards, one storing wave per GROUP of
+// bpw boards (XCD-contiguous groups); the wave writes its boards one after the other, every ply.
+__global__ __launch_bounds__(64) void p_persist_group(float* out, int n, int T, int bpw) {
+  const int w = blockIdx.x, lane = threadIdx.x, G = gridDim.x;
+  const int grp = (w & 7) * (G >> 3) + (w >> 3);
+  for (int t = 0; t < T; ++t)
+    for (int i = 0; i < bpw; ++i) {
+      float* o = out + ((size_t)t * n + (size_t)grp * bpw + i) * FB;
+      for (int pl = 0; pl < 25; ++pl) {
+        float v = (float)(pl + t);
+        uf4 val = {v, v + 1, v + 2, v + 3};
+        *(uf4*)(o + pl * NP + 4 * lane) = val;
+        if (lane < 26) *(uf4*)(o + pl * NP + 256 + 4 * lane) = val;
+        if (lane == 26) o[pl * NP + 360] = v;
+      }
+    }
+}
+static void run_group(float* out, int n, int T, int reps) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int bpw = 1; bpw <= 16 && n / bpw >= 64; bpw *= 2) {
+    for (int r = 0; r < reps + 1; ++r) { if (r == 1) hipEventRecord(e0); hipLaunchKernelGGL(p_persist_group, dim3(n / bpw), dim3(64), 0, 0, out, n, T, bpw); }
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("n=%d T=%d one storing wave per %2d boards (%5d waves)  %8.3f us per ply  %7.1f GB/s\n", n, T, bpw, n / bpw,
+           ms * 1e3 / T, (double)n * T * FB * 4 / (ms * 1e-3) / 1e9);
+  }
+}
+
+// expander candidates with ONE sequential stream per board (the shape that reaches 5.46 TB/s as a pure store):
+// board b of ply t from the packed record comp[t][b][368].  Variant 0: one wave per board, next record
+// prefetched into registers; variant 1: two waves per board, wave 0 only loads records into an LDS ring two
+// plies ahead (its vmcnt sees loads only), wave 1 expands and stores.
+template <int VAR>
+__global__ __launch_bounds__(VAR ? 128 : 64) void expand_stream(const uint32_t* __restrict__ comp, const float* __restrict__ lut,
+                                                                float* __restrict__ out, int n, int T) {
+  __shared__ float slut[2048];
+  __shared__ uint32_t ring[VAR ? 3 : 1][CW];
+  const int nthr = VAR ? 128 : 64;
+  for (int i = threadIdx.x; i < 2048; i += nthr) slut[i] = lut[i];
+  const int w0 = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = (w0 & 7) * (n >> 3) + (w0 >> 3);
+  const int qa = 4 * lane, qb = lane < 26 ? 256 + 4 * lane : NP - 4;
+  const bool act_b = lane <= 26;
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  struct __attribute__((packed, aligned(4))) uu4 { uint32_t x, y, z, w; };
+#define EXPAND_PLANES(o, d, hdr)                                                                          \
+  do {                                                                                                    \
+    const uint32_t our = (hdr) & 3u, has = (hdr) >> 2;                                                    \
+    _Pragma("unroll") for (int pl = 0; pl < 25; ++pl) {                                                   \
+      float v[8];                                                                                         \
+      const bool zero = pl == 12 || pl == 13 || pl >= 16;                                                 \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) v[i] = zero ? 0.f : plane_val(pl, d[i], our, has, slut); \
+      uf4 va = {v[0], v[1], v[2], v[3]}, vb = {v[4], v[5], v[6], v[7]};                                   \
+      *(uf4*)((o) + pl * NP + qa) = va;                                                                   \
+      if (act_b) *(uf4*)((o) + pl * NP + qb) = vb;                                                        \
+    }                                                                                                     \
+  } while (0)
+  if (VAR == 0) {
+    __syncthreads();
+    uint32_t d[8], nd[8], hdr, nhdr;
+    const uint32_t* c = comp + (size_t)b * CW;
+    { uu4 a = *(const uu4*)(c + qa), bb = *(const uu4*)(c + qb); nd[0] = a.x; nd[1] = a.y; nd[2] = a.z; nd[3] = a.w; nd[4] = bb.x; nd[5] = bb.y; nd[6] = bb.z; nd[7] = bb.w; nhdr = c[NP]; }
+    for (int t = 0; t < T; ++t) {
+      for (int i = 0; i < 8; ++i) d[i] = nd[i];
+      hdr = nhdr;
+      if (t + 1 < T) {
+        const uint32_t* c2 = comp + ((size_t)(t + 1) * n + b) * CW;
+        uu4 a = *(const uu4*)(c2 + qa), bb = *(const uu4*)(c2 + qb);
+        nd[0] = a.x; nd[1] = a.y; nd[2] = a.z; nd[3] = a.w; nd[4] = bb.x; nd[5] = bb.y; nd[6] = bb.z; nd[7] = bb.w; nhdr = c2[NP];
+      }
+      float* o = out + ((size_t)t * n + b) * FB;
+      EXPAND_PLANES(o, d, hdr);
+    }
+  } else {
+    // wave 0: loader, two plies ahead; wave 1: storer.  One barrier per ply.
+    if (wave == 0) {
+      for (int pre = 0; pre < 2 && pre < T; ++pre) {
+        const uint32_t* c = comp + ((size_t)pre * n + b) * CW;
+        for (int i = lane; i < CW; i += 64) ring[pre][i] = c[i];
+      }
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      if (wave == 0) {
+        if (t + 2 < T) {
+          const uint32_t* c = comp + ((size_t)(t + 2) * n + b) * CW;
+          uint32_t* r = ring[(t + 2) % 3];
+          for (int i = lane; i < CW; i += 64) r[i] = c[i];
+        }
+      } else {
+        const uint32_t* r = ring[t % 3];
+        uint32_t d[8];
+        for (int i = 0; i < 4; ++i) { d[i] = r[qa + i]; d[4 + i] = r[qb + i]; }
+        const uint32_t hdr = r[NP];
+        float* o = out + ((size_t)t * n + b) * FB;
+        EXPAND_PLANES(o, d, hdr);
+      }
+      __syncthreads();
+    }
+  }
+#undef EXPAND_PLANES
+}
+static void run_expand_stream(float* out, int n, int T, int reps) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int nbp = n * T;
+  uint32_t* comp; float* lut;
+  hipMalloc(&comp, (size_t)(nbp + 16) * CW * 4); hipMalloc(&lut, 2048 * 4);
+  hipLaunchKernelGGL(init_comp, dim3(1024), dim3(256), 0, 0, comp, (size_t)(nbp + 16) * CW);
+  hipMemset(lut, 0, 2048 * 4); hipDeviceSynchronize();
+  const double bytes = (double)nbp * FB * 4;
+  float ms;
+  for (int var = 0; var < 2; ++var) {
+    for (int r = 0; r < reps + 1; ++r) {
+      if (r == 1) hipEventRecord(e0);
+      if (var == 0) hipLaunchKernelGGL(expand_stream<0>, dim3(n), dim3(64), 0, 0, comp, lut, out, n, T);
+      else hipLaunchKernelGGL(expand_stream<1>, dim3(n), dim3(128), 0, 0, comp, lut, out, n, T);
+    }
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("n=%d T=%d expand_stream variant %d (%s)  %8.3f us per ply  %7.1f GB/s of planes\n", n, T, var,
+           var ? "loader wave + storing wave" : "one wave, register prefetch", ms * 1e3 / T, bytes / (ms * 1e-3) / 1e9);
+  }
+}
 static void run_front(float* out, int n, int T, int reps) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int nbp = n * T;
@@ -368,6 +525,9 @@ int main(int argc, char** argv) {
   const int front = argc > 4 ? atoi(argv[4]) : 0; // 1: the two-stage (expander) probes over n*T board-plies
   float* out;
   if (hipMalloc(&out, (size_t)n * (T > 0 ? T : 1) * FB * 4 + 64) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+  if (front == 5) { run_expand_stream(out, n, T, reps); return 0; }
+  if (front == 4) { run_group(out, n, T, reps); return 0; }
+  if (front == 3) { run_split(out, n, T, reps); return 0; }
   if (front == 2) { run_map(out, n, T, reps); return 0; }
   if (front) { run_front(out, n, T, reps); return 0; }
   if (T > 0) { run_persist(out, n, T, reps); run_throttled(out, n, T, reps); return 0; }
