@@ -41,7 +41,6 @@ REC_BYTES = 1632                         # packed board record: read once + writ
 ALG_BYTES_MOVE = 4                       # int32 move written per board per ply (generator)
 ALG_BYTES_PER_BOARD = ALG_BYTES_PLANES + ALG_BYTES_LEGAL + 2 * REC_BYTES      # launch per ply
 ALG_BYTES_PER_BOARD_PLY = ALG_BYTES_PLANES + ALG_BYTES_LEGAL + ALG_BYTES_MOVE  # generator, per ply
-PACK_BYTES = 368 * 4                     # packed sample per board-ply between the generator's two stages
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -63,16 +62,15 @@ def cpu_baseline(budget_sec=12.0):
     }
 
 
-def measured_traffic(boards, plies_per_launch, kernel="k_generate"):
-    """HBM bytes per launch of the dominant kernel from the PMC passes of this round (FETCH_SIZE x2 +
+def measured_traffic(boards, plies_per_launch):
+    """HBM bytes per launch of the generator kernel from the PMC passes of this round (FETCH_SIZE x2 +
     WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes; collected by tools/profile_round.sh on
     this same command and committed as profiles/r01_pmc.json), scaled to this run's plies per launch
-    (the kernel writes the same bytes for every ply).  None when no pass exists for this batch size
-    and kernel."""
+    (the kernel writes the same bytes for every ply).  None when no pass exists for this batch size."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
             d = json.load(f)
-        if int(d["boards"]) != boards or kernel not in d["kernel"]:
+        if int(d["boards"]) != boards or "k_generate" not in d["kernel"]:
             return None
         return float(d["traffic_bytes"]) * plies_per_launch / float(d["plies_per_launch"])
     except (OSError, ValueError, KeyError):
@@ -157,13 +155,7 @@ def main():
     env.timer_end()
     torch.cuda.synchronize()
     launches = -(-args.steps // T)
-    kernel_ms = env.timer_ms() / launches            # HIP events on the launch stream; average goenv_generate call
-    # two-stage generator: the dominant kernel is the expander (k_expand), one launch per chunk of plies on
-    # the library's second stream; its events bracket the same region on THAT stream
-    chunk = env.generate_chunk()
-    exp_ms = env.timer_expand_ms()
-    two_stage = exp_ms > 0
-    exp_launches = launches * -(-T // chunk) if args.steps % T == 0 else None
+    kernel_ms = env.timer_ms() / launches            # HIP events on the launch stream; average launch
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -176,21 +168,8 @@ def main():
     stats = reduce_stats(env.stats_tensor()).cpu().tolist()
 
     value = world * B * args.steps / elapsed
-    if two_stage and exp_launches:
-        # per expander launch: planes written + packed samples read, for B boards x (average) chunk plies
-        plies_exp = args.steps / exp_launches
-        kernel, kernel_ms = "k_expand", exp_ms / exp_launches
-        alg_launch = B * plies_exp * (ALG_BYTES_PLANES + PACK_BYTES)
-        per_ply, per_launch = ALG_BYTES_PLANES + PACK_BYTES, 0
-        traffic = measured_traffic(B, plies_exp, "k_expand")
-    else:
-        kernel = "k_generate"
-        alg_launch = B * (args.steps / launches * ALG_BYTES_PER_BOARD_PLY + 2 * REC_BYTES)   # average launch
-        per_ply, per_launch = ALG_BYTES_PER_BOARD_PLY, 2 * REC_BYTES
-        traffic = measured_traffic(B, args.steps / launches)
+    alg_launch = B * (args.steps / launches * ALG_BYTES_PER_BOARD_PLY + 2 * REC_BYTES)   # average launch
     achieved = alg_launch / (kernel_ms * 1e-3) / 1e9
-    # every byte the whole step moves, over the wall time of the step (both kernels of the two-stage path)
-    step_bytes = ALG_BYTES_PER_BOARD_PLY + (2 * PACK_BYTES if two_stage else 0)
     out = {
         "metric": "19x19 Go moves/sec (node, 1/2/4/8 GPU) + feature-extract HBM GB/s",
         "value": value, "unit": "moves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -199,18 +178,16 @@ def main():
         "config": {"workload": "cfg2: %d concurrent 19x19 games per GPU, on-device uniform-random legal-move "
                                "playouts to the end (scored, counted, restarted in place); every ply of every "
                                "board = rules update + legal mask + 25 planes + the move, written to slot t of "
-                               "device ring buffers by goenv_generate (%d plies per call%s)"
-                               % (B, T, ", two stages: persistent rules kernel -> packed samples -> expander, "
-                                        "chunks of %d plies" % chunk if two_stage else ", one persistent kernel"),
+                               "device ring buffers by the persistent generator (goenv_generate, %d plies per "
+                               "launch)" % (B, T),
                    "boards_per_gpu": B, "global_boards": world * B, "ply_cap": 722,
                    "plies_per_launch": args.steps / launches, "launches": launches, "parallelism": "shard%d" % world, "collective_backend": backend if world > 1 else None},
-        "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "roofline": {"bound": "hbm", "kernel": "k_generate", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B, args.steps / launches),
                      "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc.md)",
                      "algorithmic_bytes_per_launch": alg_launch,
-                     "bytes_per_board_ply": per_ply, "record_bytes_per_board_launch": per_launch,
-                     "kernel_ms": kernel_ms,
-                     "whole_step_GBps": B * args.steps * step_bytes / elapsed / 1e9},
+                     "bytes_per_board_ply": ALG_BYTES_PER_BOARD_PLY, "record_bytes_per_board_launch": 2 * REC_BYTES,
+                     "kernel_ms": kernel_ms},
         "feature_extract_GBps": achieved,
         "stats": {"games": stats[0], "black_wins": stats[1], "white_wins": stats[2], "plies": stats[4],
                   "max_len": stats[9], "ply_cap_hits": stats[8]},

@@ -47,7 +47,6 @@ struct PlyParams {
   float lut1;       // lut[1]
   int zero_first;   // constant planes are stored at kernel start (small batches)
   int xcd_map;      // rows dealt to workgroups so that each XCD owns a contiguous run (xcd_row)
-  uint32_t* pack;   // k_generate, two-stage: packed samples [n_plies][n][PACK_DWORDS] instead of planes
 };
 
 #ifdef GOENV_STAMPS
@@ -647,9 +646,7 @@ __global__ __launch_bounds__(64 * NW) void k_generate(PlyParams P, int n_plies, 
     if (actions_ring && g.tid == 0) actions_ring[row] = a;
     if (P.legal) write_legal(g, o, P.legal + row * NPTS);
     STAMP(11);
-    if (P.pack) {
-      write_packed(L, g, lab, lastp, s, P.aug ? (P.aug[b] & 7) : 0, P.pack + row * PACK_DWORDS);
-    } else if (P.feat) {
+    if (P.feat) {
       const int aug = P.aug ? (P.aug[b] & 7) : 0;
       write_features<NW, true, false>(L, g, lab, lastp, s, aug, P.lut, P.feat + row * GOENV_FEAT_FLOATS, hv_none, -1,
                                       P.lut1, P.stamps);
@@ -657,55 +654,6 @@ __global__ __launch_bounds__(64 * NW) void k_generate(PlyParams P, int n_plies, 
     STAMP(12);
   }
   store_board(rec, g, lab, lastp, o, s);
-}
-
-// Second stage of the two-stage generator: the 25 planes of n boards x n_plies plies from the packed samples
-// k_generate left behind.  ONE wave per board writes that board's sample of ply 0, 1, ... as a single
-// ascending store stream (plane-major, two dwordx4 wave-stores per plane, as write_features) -- the shape
-// the memory side takes fastest (tools/store_bench.hip run_split / run_group: 5.46 TB/s against 4.90 TB/s
-// for two storing waves per board).  Four boards share a workgroup and its LDS copy of the history table;
-// the next ply's packed dwords are loaded before this ply's stores are issued.
-__global__ __launch_bounds__(256) void k_expand(const uint32_t* __restrict__ pack, const float* __restrict__ lut,
-                                                float* __restrict__ feat, int n, int n_plies, int xcd_map) {
-  __shared__ float slut[HIST_LUT_N];
-  for (int i = threadIdx.x; i < HIST_LUT_N; i += 256) slut[i] = lut[i];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int groups = (n + 3) >> 2;
-  if ((int)blockIdx.x >= groups) return;
-  const int b = 4 * xcd_row(blockIdx.x, groups, xcd_map) + wave;
-  if (b >= n) return;
-  const int qa = 4 * lane, qb = lane < 26 ? 256 + 4 * lane : NPTS - 4;
-  const bool act_b = lane <= 26;
-  struct __attribute__((packed, aligned(4))) u32x4u { uint32_t x, y, z, w; };
-  uint32_t d[8], nd[8], hdr, nhdr;
-  {
-    const uint32_t* c = pack + (size_t)b * PACK_DWORDS;
-    const u32x4u a = *reinterpret_cast<const u32x4u*>(c + qa), e = *reinterpret_cast<const u32x4u*>(c + qb);
-    nd[0] = a.x; nd[1] = a.y; nd[2] = a.z; nd[3] = a.w; nd[4] = e.x; nd[5] = e.y; nd[6] = e.z; nd[7] = e.w;
-    nhdr = c[NPTS];
-  }
-  for (int t = 0; t < n_plies; ++t) {
-    GO_UNROLL
-    for (int i = 0; i < 8; ++i) d[i] = nd[i];
-    hdr = nhdr;
-    if (t + 1 < n_plies) {
-      const uint32_t* c = pack + ((size_t)(t + 1) * n + b) * PACK_DWORDS;
-      const u32x4u a = *reinterpret_cast<const u32x4u*>(c + qa), e = *reinterpret_cast<const u32x4u*>(c + qb);
-      nd[0] = a.x; nd[1] = a.y; nd[2] = a.z; nd[3] = a.w; nd[4] = e.x; nd[5] = e.y; nd[6] = e.z; nd[7] = e.w;
-      nhdr = c[NPTS];
-    }
-    const uint32_t our = hdr & 3u, has = hdr >> 2;
-    float* out = feat + ((size_t)t * n + b) * GOENV_FEAT_FLOATS;
-    GO_UNROLL
-    for (int pl = 0; pl < GOENV_NUM_PLANES; ++pl) {
-      float v[8];
-      GO_UNROLL
-      for (int i = 0; i < 8; ++i) v[i] = packed_plane(pl, d[i], our, has, slut);
-      store4<false>(out + pl * NPTS + qa, v[0], v[1], v[2], v[3]);
-      if (act_b) store4<false>(out + pl * NPTS + qb, v[4], v[5], v[6], v[7]);
-    }
-  }
 }
 
 // Replay of given move lists (SGF records packed on the host): row b applies
@@ -878,15 +826,6 @@ struct goenv_ctx {
   hipStream_t part_stream[GOENV_MAX_PARTS];  // goenv_ply_repeat_parts; created on first use
   hipEvent_t part_event[GOENV_MAX_PARTS + 1];
   int parts_ready;
-  // two-stage generator (goenv_generate): packed samples of a chunk of plies, double-buffered; the expander
-  // runs on a stream of the library's own, under the rules kernel of the next chunk.  Created on first use.
-  int two_stage;             // -1 = by batch size, 0 / 1 pinned (GOENV_TWO_STAGE, tuning only)
-  uint32_t* pack[2];
-  int pack_plies;            // plies per chunk the buffers hold
-  hipStream_t exp_stream;
-  hipEvent_t ev_rules[2], ev_exp[2];   // chunk's rules kernel done / chunk's expander done
-  hipEvent_t ev2, ev3;       // goenv_timer_*: the same region on the expander's stream
-  int exp_ready;
 };
 
 // The standalone feature kernel has no rules phase that staggers its waves' stores: mid-size
@@ -961,50 +900,6 @@ struct DeviceScope {
   DeviceScope dev_scope_((c)->device);        \
   if (dev_scope_.err != hipSuccess) return fail("selecting the context's device", dev_scope_.err)
 
-// Two-stage generator resources.  Nothing is left behind when a step fails.
-static void release_two_stage(goenv_ctx* c) {
-  for (int k = 0; k < 2; ++k) {
-    if (c->pack[k]) (void)hipFree(c->pack[k]);
-    if (c->ev_rules[k]) (void)hipEventDestroy(c->ev_rules[k]);
-    if (c->ev_exp[k]) (void)hipEventDestroy(c->ev_exp[k]);
-    c->pack[k] = nullptr; c->ev_rules[k] = nullptr; c->ev_exp[k] = nullptr;
-  }
-  if (c->ev2) (void)hipEventDestroy(c->ev2);
-  if (c->ev3) (void)hipEventDestroy(c->ev3);
-  if (c->exp_stream) (void)hipStreamDestroy(c->exp_stream);
-  c->ev2 = c->ev3 = nullptr; c->exp_stream = nullptr; c->exp_ready = 0; c->pack_plies = 0;
-}
-
-// Plies per chunk: the packed samples of a chunk (n x plies x 1,472 B, twice) should stay within the
-// Infinity Cache beside the plane stream, and a chunk should be long enough to amortise its two launches.
-static int two_stage_chunk(const goenv_ctx* c) {
-  const size_t per_ply = (size_t)c->n * PACK_DWORDS * sizeof(uint32_t);
-  size_t t = ((size_t)48 << 20) / per_ply;
-  return (int)(t < 1 ? 1 : (t > 16 ? 16 : t));
-}
-
-static int ensure_two_stage(goenv_ctx* c) {
-  if (c->exp_ready) return 0;
-  const int plies = two_stage_chunk(c);
-  const size_t bytes = (size_t)c->n * plies * PACK_DWORDS * sizeof(uint32_t);
-  hipError_t e = hipSuccess;
-  for (int k = 0; k < 2 && e == hipSuccess; ++k) {
-    if ((e = hipMalloc((void**)&c->pack[k], bytes)) != hipSuccess) break;
-    if ((e = hipEventCreateWithFlags(&c->ev_rules[k], hipEventDisableTiming)) != hipSuccess) break;
-    e = hipEventCreateWithFlags(&c->ev_exp[k], hipEventDisableTiming);
-  }
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->exp_stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipEventCreate(&c->ev2);
-  if (e == hipSuccess) e = hipEventCreate(&c->ev3);
-  if (e != hipSuccess) {
-    release_two_stage(c);
-    return fail("goenv_generate: setting up the two-stage generator", e);
-  }
-  c->pack_plies = plies;
-  c->exp_ready = 1;
-  return 0;
-}
-
 extern "C" {
 
 int goenv_version(void) { return 1; }
@@ -1027,8 +922,6 @@ int goenv_create(int device, int n_boards, uint64_t seed, int64_t board_id_base,
   if (const char* e = getenv("GOENV_ZERO_FIRST")) c->zero_first = atoi(e) & 3;
   c->xcd_map = 1;
   if (const char* e = getenv("GOENV_XCD_MAP")) c->xcd_map = atoi(e) ? 1 : 0;
-  c->two_stage = -1;
-  if (const char* e = getenv("GOENV_TWO_STAGE")) c->two_stage = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GOENV_WAVES_PER_BOARD")) {
     const int v = atoi(e);
     if (v == 1 || v == 2 || v == 3 || v == 6) c->nw = v;
@@ -1079,7 +972,6 @@ int goenv_destroy(goenv_ctx* c) {
     for (int i = 0; i < GOENV_MAX_PARTS; ++i) (void)hipStreamDestroy(c->part_stream[i]);
     for (int i = 0; i <= GOENV_MAX_PARTS; ++i) (void)hipEventDestroy(c->part_event[i]);
   }
-  release_two_stage(c);
   delete c;
   return 0;
 }
@@ -1413,39 +1305,8 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
                             nullptr, nullptr);
   // persistent launch: boards drift apart, two waves per board hide the rest (tools/time_generate.py)
   const int nw = c->nw ? c->nw : (c->n <= 4096 ? 2 : 3);
-  const bool two_stage = feat_ring && c->two_stage == 1;   // not yet the default: GOENV_TWO_STAGE=1 turns it on
-  if (!two_stage) {
-    GO_LAUNCH(nw, k_generate, c->n, S(stream), P, n_plies, actions_ring);
-    HIPCHK(hipGetLastError());
-    return 0;
-  }
-  // Two stages.  The rules kernel (k_generate with P.pack) plays a chunk of plies and leaves 1,472 B of packed
-  // sample per board-ply (+ mask and move, straight into the rings); k_expand turns a chunk into planes on the
-  // library's second stream while the rules kernel is already on the next chunk.  The planes thus leave the
-  // chip as one sequential stream per board from a wave that does nothing else, and no wave of the rules
-  // kernel ever stands in a store queue.  Chunk i uses packed buffer i % 2; the rules kernel of chunk i + 2
-  // waits for the expander of chunk i; the caller's stream is joined to the last expander at the end.
-  if (ensure_two_stage(c)) return -1;
-  P.feat = nullptr;
-  const int chunk = c->pack_plies;
-  int last = -1;
-  for (int t0 = 0, i = 0; t0 < n_plies; t0 += chunk, ++i) {
-    const int k = i & 1, tc = n_plies - t0 < chunk ? n_plies - t0 : chunk;
-    // the expander that read this buffer last (this call's chunk i - 2, or an earlier call's) is done
-    HIPCHK(hipStreamWaitEvent(S(stream), c->ev_exp[k], 0));
-    P.pack = c->pack[k];
-    P.legal = legal_ring ? legal_ring + (size_t)t0 * c->n * GOENV_NUM_POINTS : nullptr;
-    GO_LAUNCH(nw, k_generate, c->n, S(stream), P, tc, actions_ring ? actions_ring + (size_t)t0 * c->n : nullptr);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev_rules[k], S(stream)));
-    HIPCHK(hipStreamWaitEvent(c->exp_stream, c->ev_rules[k], 0));
-    hipLaunchKernelGGL(k_expand, dim3((c->n + 3) / 4), dim3(256), 0, c->exp_stream, c->pack[k], c->lut,
-                       feat_ring + (size_t)t0 * c->n * GOENV_FEAT_FLOATS, c->n, tc, c->xcd_map);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev_exp[k], c->exp_stream));
-    last = k;
-  }
-  HIPCHK(hipStreamWaitEvent(S(stream), c->ev_exp[last], 0));
+  GO_LAUNCH(nw, k_generate, c->n, S(stream), P, n_plies, actions_ring);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 
@@ -1495,17 +1356,12 @@ int goenv_timer_begin(goenv_ctx* c, void* stream) {
   if (!c) return fail("goenv_timer_begin: ctx is NULL");
   ON_DEVICE_OF(c);
   HIPCHK(hipEventRecord(c->ev0, S(stream)));
-  if (c->exp_ready) {  // the same point on the expander's stream
-    HIPCHK(hipStreamWaitEvent(c->exp_stream, c->ev0, 0));
-    HIPCHK(hipEventRecord(c->ev2, c->exp_stream));
-  }
   return 0;
 }
 int goenv_timer_end(goenv_ctx* c, void* stream) {
   if (!c) return fail("goenv_timer_end: ctx is NULL");
   ON_DEVICE_OF(c);
   HIPCHK(hipEventRecord(c->ev1, S(stream)));
-  if (c->exp_ready) HIPCHK(hipEventRecord(c->ev3, c->exp_stream));
   return 0;
 }
 float goenv_timer_ms(goenv_ctx* c) {
@@ -1516,15 +1372,6 @@ float goenv_timer_ms(goenv_ctx* c) {
   if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.f;
   return ms;
 }
-float goenv_timer_expand_ms(goenv_ctx* c) {
-  if (!c || !c->exp_ready) return -1.f;
-  DeviceScope scope(c->device);
-  float ms = -1.f;
-  if (hipEventSynchronize(c->ev3) != hipSuccess) return -1.f;
-  if (hipEventElapsedTime(&ms, c->ev2, c->ev3) != hipSuccess) return -1.f;
-  return ms;
-}
-int goenv_generate_chunk(const goenv_ctx* c) { return c ? (c->exp_ready ? c->pack_plies : two_stage_chunk(c)) : 0; }
 
 static int d4_fwd(int code, int x, int y) {
   const int rot = code % 4;

@@ -942,85 +942,6 @@ __device__ __forceinline__ void write_features(BoardLds<NW>& L, const Geo<NW>& g
 #undef FSTAMP
 }
 
-// ---- packed sample (two-stage generator) ---------------------------------------------------------------
-// Everything Extract needs of one position, one dword per OUTPUT point q (D4 code applied) plus a header:
-//   bits 0-1 colour, 2-3 liberty class, 4 ko point (GetSimpleKoLocation), 5-15 age = ply - last_placed clamped
-//   to the history table (0 under empties), 16-23 / 24-31 L1 distance to the nearest black / white stone.
-//   dword 361 = side to move | (black present) << 2 | (white present) << 3.
-// PACK_DWORDS * 4 = 1,472 B per board-ply instead of 36,100 B: the rules kernel leaves this behind and a
-// separate kernel (k_expand) turns it into the 25 planes as ONE sequential store stream per board.
-constexpr int PACK_DWORDS = TAB_N;
-
-template <int NW>
-__device__ __forceinline__ void write_packed(BoardLds<NW>& L, const Geo<NW>& g, const uint32_t lab[],
-                                             const uint32_t lastp[], const Scalars& s, int aug,
-                                             uint32_t* __restrict__ out) {
-  constexpr int K = Geo<NW>::K;
-  unsigned long long wb[NWORDS + 1], ww[NWORDS + 1];
-  GO_UNROLL
-  for (int k = 0; k < K; ++k) {
-    const unsigned long long bb = __ballot(col_of(lab[k]) == 1), bw = __ballot(col_of(lab[k]) == 2);
-    if (NW == 1) { wb[k] = bb; ww[k] = bw; }
-    else if (g.lane == 0) { L.xcol[NW * k + g.wave] = bb; L.xcol[NWORDS + NW * k + g.wave] = bw; }
-  }
-  const int ko_p = (s.koage == 0 && s.ko >= 0) ? s.ko : -1;  // GetSimpleKoLocation, board.cc:337-344
-  GO_UNROLL
-  for (int k = 0; k < K; ++k) {
-    if (g.p[k] < NPTS) {
-      uint32_t d = typ_of(lab[k]);
-      if (g.p[k] == ko_p) d |= 16u;
-      if (lab[k]) {
-        int age = s.ply - (int)lastp[k];
-        age = age < 0 ? 0 : (age > HIST_LUT_N - 1 ? HIST_LUT_N - 1 : age);
-        d |= (uint32_t)age << 5;
-      }
-      const int q = aug ? d4_dest(aug, g.p[k]) : g.p[k];
-      L.desc[q] = d;
-    }
-  }
-  WSYNC();
-  if (NW > 1) {
-    GO_UNROLL
-    for (int j = 0; j < NWORDS; ++j) { wb[j] = uni64(L.xcol[j]); ww[j] = uni64(L.xcol[NWORDS + j]); }
-  }
-  wb[NWORDS] = 0; ww[NWORDS] = 0;
-  uint32_t has = 0;
-  GO_UNROLL
-  for (int j = 0; j < NWORDS; ++j) { if (wb[j]) has |= 1u; if (ww[j]) has |= 2u; }
-  if (g.wave == 0) distance_lines(L, g.lane, wb, ww, aug);
-  WSYNC();
-  GO_UNROLL
-  for (int k = 0; k < K; ++k) {
-    const int q = g.p[k];   // now an OUTPUT index: the tables are in output order
-    if (q < NPTS) out[q] = L.desc[q] | (uint32_t)L.dist[0][q] << 16 | (uint32_t)L.dist[1][q] << 24;
-  }
-  if (g.tid == 0) out[NPTS] = (uint32_t)s.next | has << 2;
-}
-
-// One plane value from a packed dword (the 14 planes that carry data; BoardFeature::Extract and its
-// fillers, go/board_feature.cc:83-160,175-195).  `lut` = the history table.
-__device__ __forceinline__ float packed_plane(int pl, uint32_t W, uint32_t our, uint32_t has, const float* lut) {
-  const uint32_t col = W & 3u, cls = (W >> 2) & 3u, opp = 3u - our;
-  const bool mine = col == our, theirs = col == opp;
-  switch (pl) {
-    case 0: return (mine && cls == 1) ? 1.f : 0.f;
-    case 1: return (mine && cls == 2) ? 1.f : 0.f;
-    case 2: return (mine && cls != 1 && cls != 2) ? 1.f : 0.f;  // literally "else", board_feature.cc:93
-    case 3: return (theirs && cls == 1) ? 1.f : 0.f;
-    case 4: return (theirs && cls == 2) ? 1.f : 0.f;
-    case 5: return (theirs && cls != 1 && cls != 2) ? 1.f : 0.f;
-    case 6: return (W & 16u) ? 1.f : 0.f;
-    case 7: return mine ? 1.f : 0.f;
-    case 8: return theirs ? 1.f : 0.f;
-    case 9: return col == 0 ? 1.f : 0.f;
-    case 10: return mine ? lut[(W >> 5) & 0x7ffu] : 0.f;
-    case 11: return theirs ? lut[(W >> 5) & 0x7ffu] : 0.f;
-    case 14: return ((has >> (our - 1)) & 1u) ? (float)((W >> (our == 1 ? 16 : 24)) & 0xffu) : 10000.f;
-    case 15: return ((has >> (opp - 1)) & 1u) ? (float)((W >> (opp == 1 ? 16 : 24)) & 0xffu) : 10000.f;
-    default: return 0.f;   // 12, 13, 16..24: never filled (board_feature.h:13-28)
-  }
-}
-
 template <int NW>
 __device__ __forceinline__ void write_legal(const Geo<NW>& g, const Own<NW>& o, uint8_t* __restrict__ out) {
   GO_UNROLL

@@ -80,8 +80,6 @@ _SIGS = {
     "goenv_timer_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "goenv_timer_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "goenv_timer_ms": (C.c_float, [C.c_void_p]),
-    "goenv_timer_expand_ms": (C.c_float, [C.c_void_p]),
-    "goenv_generate_chunk": (C.c_int, [C.c_void_p]),
     "goenv_aug_action": (C.c_int, [C.c_int, C.c_int]),
     "goenv_aug_action_inv": (C.c_int, [C.c_int, C.c_int]),
 }
@@ -394,14 +392,6 @@ class GoEnv:
 
     def timer_ms(self):
         return float(self.lib.goenv_timer_ms(self._h))
-
-    def timer_expand_ms(self):
-        """The timed region as seen on the expander's stream (two-stage generator); -1 if it never ran."""
-        return float(self.lib.goenv_timer_expand_ms(self._h))
-
-    def generate_chunk(self):
-        """Plies per chunk of the two-stage generator (one rules launch + one expander launch each)."""
-        return int(self.lib.goenv_generate_chunk(self._h))
 
 
 class _CudaArray:

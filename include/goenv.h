@@ -306,24 +306,16 @@ int goenv_host_free(void* p);
 int goenv_playout(goenv_ctx* ctx, int16_t* moves_out, int max_record, int32_t* nmoves_out,
                   void* stream);
 
-/* goenv_generate: n_plies plies of the on-device cfg-2 policy on EVERY board (finished games are
- * scored, counted and restarted in place, as GOENV_F_AUTO_RESTART does), for callers without a
- * model in the loop (random-playout data generation).  Ply t's outputs go to slot t of the
- * caller's ring buffers: feat_ring float32 [n_plies][n][25][19][19], legal_ring u8
- * [n_plies][n][361], actions_ring int32 [n_plies][n]; any may be NULL.  Results equal n_plies
- * calls of goenv_ply(RANDOM_POLICY | AUTO_RESTART).  aug_codes: int32 [n] or NULL.
- * With a feat_ring the work runs in two stages, in chunks of goenv_generate_chunk() plies: a
- * persistent rules kernel on `stream` leaves a packed sample (1,472 B) per board-ply in a buffer of
- * the library's, and an expander on a stream of the library's writes the planes from it while the
- * rules kernel plays the next chunk; `stream` is joined to the last expander before the call
- * returns, so stream order holds for the caller as for every other entry point.  The first such call
- * on a context allocates the two packed buffers (hipMalloc).  Successive calls on one context must
- * be ordered on one stream (or synchronised by the caller).  No counterpart in the reference (its
- * playouts run one thread per game on the CPU). */
+/* goenv_generate: n_plies plies of the on-device cfg-2 policy on EVERY board inside one
+ * persistent launch (finished games are scored, counted and restarted in place, as
+ * GOENV_F_AUTO_RESTART does), for callers without a model in the loop (random-playout data
+ * generation).  Ply t's outputs go to slot t of the caller's ring buffers:
+ * feat_ring float32 [n_plies][n][25][19][19], legal_ring u8 [n_plies][n][361], actions_ring
+ * int32 [n_plies][n]; any may be NULL.  Results equal n_plies calls of
+ * goenv_ply(RANDOM_POLICY | AUTO_RESTART).  aug_codes: int32 [n] or NULL.  No counterpart in
+ * the reference (its playouts run one thread per game on the CPU). */
 int goenv_generate(goenv_ctx* ctx, int n_plies, const int32_t* aug_codes, float* feat_ring,
                    uint8_t* legal_ring, int32_t* actions_ring, void* stream);
-/* plies per chunk of the two-stage generator for this context (>= 1) */
-int goenv_generate_chunk(const goenv_ctx* ctx);
 
 /* goenv_score: GetTrompTaylorScore(board, NULL, NULL) (go/board.cc:1584-1688)
  * into score_out float32 [n] (black minus white, no komi; 0 on an empty
@@ -381,9 +373,6 @@ int goenv_stats_clear(goenv_ctx* ctx, void* stream);
 int goenv_timer_begin(goenv_ctx* ctx, void* stream);
 int goenv_timer_end(goenv_ctx* ctx, void* stream);
 float goenv_timer_ms(goenv_ctx* ctx);
-/* the same region on the stream goenv_generate's expander runs on (first expander launch queued
- * after _begin to last one queued before _end); -1 if the two-stage generator has not run yet */
-float goenv_timer_expand_ms(goenv_ctx* ctx);
 
 /* D4 / action helpers (host, pure): go/board_feature.h:38-71.  Actions are
  * export indices; goenv_aug_action maps a board action to the action index in
