@@ -489,6 +489,48 @@ static void run_expand_stream(float* out, int n, int T, int reps) {
            var ? "loader wave + storing wave" : "one wave, register prefetch", ms * 1e3 / T, bytes / (ms * 1e-3) / 1e9);
   }
 }
+
+// does line alignment of the wave-stores matter?  One wave per board (XCD-contiguous), the board's 36,100 B as a
+// flat stream: align 0 = plane-major as the product (planes start every 1,444 B); 16 / 128 / 1024 = a head of
+// single floats up to that alignment, then dwordx4 wave-stores of 1 KB each at that alignment, then a tail.
+__global__ __launch_bounds__(64) void p_persist_flat(float* out, int n, int T, int align) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const int b = (w & 7) * (n >> 3) + (w >> 3);
+  for (int t = 0; t < T; ++t) {
+    float* o = out + ((size_t)t * n + b) * FB;
+    if (align == 0) {
+      for (int pl = 0; pl < 25; ++pl) {
+        float v = (float)(pl + t);
+        uf4 val = {v, v + 1, v + 2, v + 3};
+        *(uf4*)(o + pl * NP + 4 * lane) = val;
+        if (lane < 26) *(uf4*)(o + pl * NP + 256 + 4 * lane) = val;
+        if (lane == 26) o[pl * NP + 360] = v;
+      }
+    } else {
+      const size_t a0 = (size_t)o, a1 = (a0 + align - 1) / align * align;
+      const int head = (int)((a1 - a0) >> 2);              // floats before the aligned body
+      if (lane < head) o[lane] = 1.f;
+      if (lane + 64 < head) o[lane + 64] = 1.f;
+      if (lane + 128 < head) o[lane + 128] = 1.f;
+      if (lane + 192 < head) o[lane + 192] = 1.f;
+      const int body = (FB - head) & ~255;                  // whole 1-KB wave-stores
+      f4 val = {1.f, 2.f, 3.f, (float)t};
+      for (int i = 0; i < body; i += 256) *(f4*)(o + head + i + 4 * lane) = val;
+      for (int i = head + body + lane; i < FB; i += 64) o[i] = 2.f;
+    }
+  }
+}
+static void run_flat(float* out, int n, int T, int reps) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int al[4] = {0, 16, 128, 1024};
+  for (int a = 0; a < 4; ++a) {
+    for (int r = 0; r < reps + 1; ++r) { if (r == 1) hipEventRecord(e0); hipLaunchKernelGGL(p_persist_flat, dim3(n), dim3(64), 0, 0, out, n, T, al[a]); }
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("n=%d T=%d persistent 1 wave/board, flat stream aligned to %4d B  %8.3f us per ply  %7.1f GB/s\n", n, T, al[a],
+           ms * 1e3 / T, (double)n * T * FB * 4 / (ms * 1e-3) / 1e9);
+  }
+}
 static void run_front(float* out, int n, int T, int reps) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int nbp = n * T;
@@ -525,6 +567,7 @@ int main(int argc, char** argv) {
   const int front = argc > 4 ? atoi(argv[4]) : 0; // 1: the two-stage (expander) probes over n*T board-plies
   float* out;
   if (hipMalloc(&out, (size_t)n * (T > 0 ? T : 1) * FB * 4 + 64) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+  if (front == 6) { run_flat(out, n, T, reps); return 0; }
   if (front == 5) { run_expand_stream(out, n, T, reps); return 0; }
   if (front == 4) { run_group(out, n, T, reps); return 0; }
   if (front == 3) { run_split(out, n, T, reps); return 0; }
