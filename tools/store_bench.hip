@@ -531,6 +531,57 @@ static void run_flat(float* out, int n, int T, int reps) {
            ms * 1e3 / T, (double)n * T * FB * 4 / (ms * 1e-3) / 1e9);
   }
 }
+
+// cache-policy bits of the plane stores (gfx950: sc0, sc1, nt), persistent one wave per board, XCD-contiguous
+template <int POL>
+__device__ __forceinline__ void st_pol(float* p, f4 v) {
+  if (POL == 0) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  if (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  if (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  if (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  if (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  if (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  if (POL == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  if (POL == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+template <int POL>
+__global__ __launch_bounds__(64) void p_persist_pol(float* out, int n, int T) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const int b = (w & 7) * (n >> 3) + (w >> 3);
+  for (int t = 0; t < T; ++t) {
+    float* o = out + ((size_t)t * n + b) * FB;
+    for (int pl = 0; pl < 25; ++pl) {
+      float v = (float)(pl + t);
+      f4 val = {v, v + 1, v + 2, v + 3};
+      st_pol<POL>(o + pl * NP + 4 * lane, val);
+      if (lane < 26) st_pol<POL>(o + pl * NP + 256 + 4 * lane, val);
+      if (lane == 26) o[pl * NP + 360] = v;
+    }
+  }
+}
+static void run_pol(float* out, int n, int T, int reps) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const char* nm[8] = {"(none)", "sc0", "sc1", "sc0 sc1", "nt", "sc0 nt", "sc1 nt", "sc0 sc1 nt"};
+  for (int pol = 0; pol < 8; ++pol) {
+    for (int r = 0; r < reps + 1; ++r) {
+      if (r == 1) hipEventRecord(e0);
+      switch (pol) {
+        case 0: hipLaunchKernelGGL(p_persist_pol<0>, dim3(n), dim3(64), 0, 0, out, n, T); break;
+        case 1: hipLaunchKernelGGL(p_persist_pol<1>, dim3(n), dim3(64), 0, 0, out, n, T); break;
+        case 2: hipLaunchKernelGGL(p_persist_pol<2>, dim3(n), dim3(64), 0, 0, out, n, T); break;
+        case 3: hipLaunchKernelGGL(p_persist_pol<3>, dim3(n), dim3(64), 0, 0, out, n, T); break;
+        case 4: hipLaunchKernelGGL(p_persist_pol<4>, dim3(n), dim3(64), 0, 0, out, n, T); break;
+        case 5: hipLaunchKernelGGL(p_persist_pol<5>, dim3(n), dim3(64), 0, 0, out, n, T); break;
+        case 6: hipLaunchKernelGGL(p_persist_pol<6>, dim3(n), dim3(64), 0, 0, out, n, T); break;
+        default: hipLaunchKernelGGL(p_persist_pol<7>, dim3(n), dim3(64), 0, 0, out, n, T); break;
+      }
+    }
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("n=%d T=%d persistent 1 wave/board, store policy %-11s %8.3f us per ply  %7.1f GB/s\n", n, T, nm[pol],
+           ms * 1e3 / T, (double)n * T * FB * 4 / (ms * 1e-3) / 1e9);
+  }
+}
 static void run_front(float* out, int n, int T, int reps) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int nbp = n * T;
@@ -567,6 +618,7 @@ int main(int argc, char** argv) {
   const int front = argc > 4 ? atoi(argv[4]) : 0; // 1: the two-stage (expander) probes over n*T board-plies
   float* out;
   if (hipMalloc(&out, (size_t)n * (T > 0 ? T : 1) * FB * 4 + 64) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+  if (front == 7) { run_pol(out, n, T, reps); return 0; }
   if (front == 6) { run_flat(out, n, T, reps); return 0; }
   if (front == 5) { run_expand_stream(out, n, T, reps); return 0; }
   if (front == 4) { run_group(out, n, T, reps); return 0; }
