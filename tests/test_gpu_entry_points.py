@@ -197,6 +197,44 @@ def test_generate_equals_per_ply_launches(goenv):
     b.close()
 
 
+@pytest.mark.parametrize("B", [1, 7, 9, 13, 100])
+def test_row_dealing_per_xcd_is_invisible(goenv, monkeypatch, B):
+    """Which workgroup takes which output row (xcd_row: every XCD a contiguous run of rows) must not show in
+    any output: ply, feature and generator kernels with the map on equal the same calls with it off, for
+    board counts that are not multiples of 8 (one board, fewer boards than XCDs, ragged last runs)."""
+    T, seed = 5, 31
+    envs = []
+    for m in ("0", "1"):
+        monkeypatch.setenv("GOENV_XCD_MAP", m)          # read by goenv_create
+        envs.append(goenv.GoEnv(B, seed=seed, max_ply=40))
+    monkeypatch.delenv("GOENV_XCD_MAP")
+    dev = envs[0].device
+    augs = ((torch.arange(B, dtype=torch.int32, device=dev) * 5) % 8).contiguous()
+    flags = goenv.F_RANDOM_POLICY | goenv.F_AUTO_RESTART
+    outs = []
+    for env in envs:
+        got = []
+        ring = (torch.zeros(T, B, 25, 19, 19, device=dev), torch.zeros(T, B, 361, dtype=torch.uint8, device=dev),
+                torch.zeros(T, B, dtype=torch.int32, device=dev))
+        feat, legal, acts = env.new(torch.float32, 25, 19, 19), env.new(torch.uint8, 361), env.new(torch.int32)
+        for _ in range(12):
+            env.generate(T, *ring, aug_codes=augs)
+            got += [t.clone() for t in ring]
+            env.ply(flags, aug_codes=augs, feat_out=feat, legal_out=legal, actions_out=acts)
+            got += [feat.clone(), legal.clone(), acts.clone()]
+            env.features(feat, augs, legal)
+            got += [feat.clone(), legal.clone()]
+        got += [v for _, v in sorted(env.get_state().items())]
+        outs.append(got)
+        env.close()
+    for i, (x, y) in enumerate(zip(*outs)):
+        if x.dtype == torch.float32:
+            x, y = x.view(torch.int32), y.view(torch.int32)
+        elif x.dtype == torch.uint16:
+            x, y = x.view(torch.int16), y.view(torch.int16)
+        assert torch.equal(x, y), i
+
+
 def test_copy_boards_branches_positions(goenv):
     """Tree-search style branching: children = copies of a parent, each stepped with its own move."""
     B, seed = 12, 8
