@@ -231,7 +231,10 @@ int goenv_ply_repeat_parts(goenv_ctx* ctx, int n_steps, int n_parts, uint32_t fl
  * idx[b] (device int32) when idx != NULL, else first + b.  Every batch array is
  * indexed by the ROW b, so a collector's batch tensors can be filled from any
  * subset of the resident boards (this is what replaces CollectorGroupT's
- * per-key memcpy, elf/state_collector.h:251-301, elf/hist.h:71-121).
+ * per-key memcpy, elf/state_collector.h:251-301, elf/hist.h:71-121).  An index outside
+ * [0, n_boards) leaves its row untouched (status -2 where a status is written); the indices of
+ * a call that MODIFIES boards (goenv_ply_sel, goenv_replay) must be distinct -- two rows on one
+ * board would race.
  *
  * goenv_ply_sel     = goenv_ply on the selection (+ optional sample record).
  * goenv_collect_sel = AIWithCommT::Act's Prepare + extract (elf/ai.h:69-80,
