@@ -834,7 +834,7 @@ static int pick_nw_features(const goenv_ctx* c, int count) {
   if (c->nw) return c->nw;
   if (count <= 512) return 6;
   if (count <= 4096) return 3;
-  if (count <= 32768) return 1;
+  if (count <= 8192) return 1;   // with the per-XCD row dealing three waves win again from 16,384 boards on
   return 3;
 }
 
