@@ -1,5 +1,14 @@
 // Diagnostic microbenchmark: how fast can one wave per board write its 9025-float feature block
 // under different store shapes?  Not part of the product.
+// Usage: store_bench <boards> <reps> [plies [mode]]      (results under profiles/r01_store_bench*.txt)
+//   plies = 0 (default)  one launch per ply, store shapes p0..p5
+//   plies < 0            plain fills of the same byte count (grid-stride / chunked / hipMemsetAsync)
+//   plies > 0, mode 0    persistent stores into ring[t][b] / ring[b][t], 1 and 3 waves per board, throttled variants
+//   mode 1  expanders with a chip-wide write front (fill_front, expand_board, expand_flat)
+//   mode 2  board <-> workgroup maps (identity, XCD-contiguous, CU-contiguous, shuffled)
+//   mode 3  plane splits between two waves of a board      mode 4  one storing wave per group of boards
+//   mode 5  stream expanders from packed samples           mode 6  alignment of the wave-stores
+//   mode 7  cache-policy bits of the stores (sc0 / sc1 / nt)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
