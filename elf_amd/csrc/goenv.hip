@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1162,6 +1163,72 @@ int goenv_features(goenv_ctx* c, const int32_t* aug_codes, float* feat_out, uint
   if (!c) return fail("goenv_features: ctx is NULL");
   if (!feat_out && !legal_out) return fail("goenv_features: no output buffer");
   return goenv_collect_sel(c, nullptr, 0, c->n, aug_codes, feat_out, legal_out, nullptr, stream);
+}
+
+// ---- goenv_features_static: the one entry point that allocates nothing ------------------------
+// Positions in, planes + legal mask out, with no context: the packed records that k_set_state
+// builds and k_features reads, and the history table, live in `scratch`, a file-scope device array
+// (one copy per GPU, held until the process ends).  Host code never uses the array's NAME as an
+// address: g_static[dev].base is what hipGetSymbolAddress returned on that device.
+constexpr size_t STATIC_LUT_BYTES = HIST_LUT_N * sizeof(float);  // 8 KB, keeps the records 256-B aligned
+static __device__ __align__(256) unsigned char scratch[STATIC_LUT_BYTES +
+                                                       (size_t)GOENV_STATIC_MAX_BOARDS * sizeof(BoardRec)];
+
+struct StaticDev {
+  unsigned char* base = nullptr;  // device address of `scratch` on this GPU
+  float lut1 = 0.f;
+  bool ready = false;
+};
+static StaticDev g_static[64];
+static std::mutex g_static_mu;
+
+// Set-up, once per device, with that device current: the array's address there, then the history
+// table (the same host-evaluated exp values goenv_create uploads) copied to its first 8 KB.
+static int static_setup(int device, StaticDev** out) {
+  std::lock_guard<std::mutex> lock(g_static_mu);
+  StaticDev& d = g_static[device];
+  if (!d.ready) {
+    void* p = nullptr;
+    HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail("goenv_features_static: hipGetSymbolAddress returned NULL");
+    std::vector<float> lut(HIST_LUT_N);
+    for (int i = 0; i < HIST_LUT_N; ++i) lut[i] = (float)exp((double)(-i) / 10.0);
+    lut[HIST_LUT_N - 1] = 0.f;
+    HIPCHK(hipMemcpy(p, lut.data(), STATIC_LUT_BYTES, hipMemcpyHostToDevice));
+    d.base = (unsigned char*)p;
+    d.lut1 = lut[1];
+    d.ready = true;
+  }
+  *out = &d;
+  return 0;
+}
+
+int goenv_features_static(int device, int n, const uint8_t* color, const uint16_t* last_placed,
+                          const int32_t* scalars, const int32_t* aug_codes, float* feat_out, uint8_t* legal_out,
+                          void* stream) {
+  if (n < 0 || n > GOENV_STATIC_MAX_BOARDS)
+    return fail("goenv_features_static: n exceeds GOENV_STATIC_MAX_BOARDS (4096 positions per call)");
+  if (device < 0 || device >= 64) return fail("goenv_features_static: device out of range");
+  if (!color || !scalars) return fail("goenv_features_static: color and scalars are required");
+  if (!feat_out && !legal_out) return fail("goenv_features_static: no output buffer");
+  DeviceScope scope(device);
+  if (scope.err != hipSuccess) return fail("goenv_features_static: selecting the device", scope.err);
+  StaticDev* d = nullptr;
+  if (static_setup(device, &d)) return -1;
+  if (n == 0) return 0;
+  BoardRec* recs = reinterpret_cast<BoardRec*>(d->base + STATIC_LUT_BYTES);
+  const float* lut = reinterpret_cast<const float*>(d->base);
+  const int nw = n <= 512 ? 6 : 3;
+  // every record row [0, n) is rewritten in full by k_set_state before k_features reads it (same
+  // stream): nothing of an earlier call is read, so nothing needs clearing
+  GO_LAUNCH(nw, k_set_state, n, S(stream), recs, n, color, last_placed, scalars);
+  HIPCHK(hipGetLastError());
+  goenv_sample_out none;
+  memset(&none, 0, sizeof(none));
+  GO_LAUNCH(nw, k_features, n, S(stream), recs, n, (const int32_t*)nullptr, 0, n, aug_codes, lut, feat_out, legal_out,
+            none, 0, d->lut1, n <= 1536 ? 2 : 0, 1);
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 int goenv_sample_policy(goenv_ctx* c, const int32_t* idx, int first, int count, const float* pi,

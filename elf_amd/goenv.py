@@ -49,6 +49,7 @@ _SIGS = {
     "goenv_set_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 3 + [C.c_void_p]),
     "goenv_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goenv_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "goenv_features_static": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p]),
     "goenv_ply": (C.c_int, [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6 + [C.c_void_p]),
     "goenv_ply_repeat": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32] + [C.c_void_p] * 6 + [C.c_void_p]),
     "goenv_ply_repeat_parts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32] + [C.c_void_p] * 6 + [C.c_void_p]),
@@ -398,6 +399,37 @@ class _CudaArray:
     def __init__(self, ptr, shape, typestr, owner):
         self.owner = owner
         self.__cuda_array_interface__ = dict(shape=shape, typestr=typestr, data=(int(ptr), False), version=2)
+
+
+STATIC_MAX_BOARDS = 4096
+
+
+def features_static(color, last_placed, scalars, feat_out=None, legal_out=None, aug_codes=None):
+    """goenv_features_static: positions -> planes + legal mask with no context and no allocation
+    (the caller owns every tensor; n <= STATIC_MAX_BOARDS)."""
+    lib = load_library()
+    dev = color.device
+    n = color.shape[0]
+
+    def check(t, dtype, shape, name):
+        if t is None:
+            return
+        if t.device != dev or t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+            raise GoEnvError("%s must be a contiguous %s tensor of shape %s on %s" % (name, dtype, tuple(shape), dev))
+    if dev.type != "cuda":
+        raise GoEnvError("features_static needs device tensors")
+    check(color, torch.uint8, (n, NUM_POINTS), "color")
+    check(last_placed, torch.uint16, (n, NUM_POINTS), "last_placed")
+    check(scalars, torch.int32, (n, 16), "scalars")
+    check(aug_codes, torch.int32, (n,), "aug_codes")
+    check(feat_out, torch.float32, (n, NUM_PLANES, 19, 19), "feat_out")
+    check(legal_out, torch.uint8, (n, NUM_POINTS), "legal_out")
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    rc = lib.goenv_features_static(index, n, _ptr(color), _ptr(last_placed), _ptr(scalars), _ptr(aug_codes),
+                                   _ptr(feat_out), _ptr(legal_out),
+                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise GoEnvError(lib.goenv_last_error().decode())
 
 
 def aug_action(code, action):

@@ -196,6 +196,25 @@ int goenv_step(goenv_ctx* ctx, const int64_t* actions, uint8_t* legal_out, int32
 int goenv_features(goenv_ctx* ctx, const int32_t* aug_codes, float* feat_out,
                    uint8_t* legal_out, void* stream);
 
+/* goenv_features_static: goenv_set_state + goenv_features without a context and WITHOUT ANY
+ * ALLOCATION.  It has no counterpart in the reference; it is for callers that cannot allocate
+ * device memory (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc) and so cannot call goenv_create.  Positions in (canonical view, as goenv_set_state:
+ * color u8 [n][361], last_placed u16 [n][361] or NULL, scalars int32 [n][16]), out
+ * BoardFeature::Extract (go/board_feature.cc:175-195) into feat_out float32 [n][25][19][19] and
+ * FindAllValidMoves (go/board.cc:763-779) into legal_out u8 [n][361]; aug_codes int32 [n] or NULL;
+ * either output may be NULL, not both.  The packed records in between and the history table live
+ * in a static device array of the library (8 KB + 4,096 x 1,632 B = 6.7 MB per GPU, held until
+ * the process ends): n > GOENV_STATIC_MAX_BOARDS is an error.  The first call on a device looks up
+ * that array's address and uploads the 8-KB history table (a synchronous copy; make one call
+ * before starting a graph capture); after that the call only enqueues two kernels on `stream`.
+ * All calls on one GPU share the array: calls that overlap on one GPU (different streams or
+ * threads) race -- order them. */
+#define GOENV_STATIC_MAX_BOARDS 4096
+int goenv_features_static(int device, int n, const uint8_t* color, const uint16_t* last_placed,
+                          const int32_t* scalars, const int32_t* aug_codes, float* feat_out,
+                          uint8_t* legal_out, void* stream);
+
 /* goenv_ply: the fused per-ply hot path (one launch): choose (flag RANDOM:
  * uniform over legal moves that do not fill an own true eye,
  * go/board.cc:1501-1552, pass if none) or take actions[b]; apply it; then

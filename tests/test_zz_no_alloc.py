@@ -1,0 +1,88 @@
+"""goenv_features_static -- the entry point that allocates nothing (include/goenv.h): its planes and
+legal masks must equal, bit for bit, those of the existing goenv_set_state + goenv_features on a
+context, on two calls in a row, the second with a smaller input (the static scratch array keeps the
+first call's records).  Also checked against the CPU oracle, and that free device memory does not
+move across a call."""
+import numpy as np
+import pytest
+
+from common import assert_planes_equal
+from oracle.pyoracle import OracleBoard
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def goenv():
+    from elf_amd import goenv as m
+    m.load_library()
+    assert torch.cuda.is_available()
+    return m
+
+
+def positions(goenv, n, seed, plies):
+    """n mid-game positions (canonical view, device tensors) from the on-device policy."""
+    env = goenv.GoEnv(n, seed=seed, max_ply=722)
+    env.ply_repeat(plies, goenv.F_RANDOM_POLICY)
+    st = env.get_state()
+    env.close()
+    return st["color"], st["last_placed"], st["scalars"]
+
+
+def via_context(goenv, color, lastp, scal, augs):
+    n = color.shape[0]
+    env = goenv.GoEnv(n, seed=1)
+    env.set_state(color, lastp, scal)
+    feat, legal = env.new(torch.float32, 25, 19, 19), env.new(torch.uint8, 361)
+    env.features(feat, augs, legal)
+    torch.cuda.synchronize()
+    env.close()
+    return feat, legal
+
+
+def test_static_entry_point_equals_context_path_twice(goenv):
+    dev = torch.device("cuda", 0)
+    for call, (n, seed, plies) in enumerate([(700, 41, 120), (93, 42, 37)]):   # the second call is smaller
+        color, lastp, scal = positions(goenv, n, seed, plies)
+        augs = ((torch.arange(n, dtype=torch.int32, device=dev) * 3 + call) % 8).contiguous()
+        want_f, want_l = via_context(goenv, color, lastp, scal, augs)
+        feat = torch.full((n, 25, 19, 19), -7.0, dtype=torch.float32, device=dev)
+        legal = torch.full((n, 361), 9, dtype=torch.uint8, device=dev)
+        if call == 1:
+            free0 = torch.cuda.mem_get_info(dev)[0]
+        goenv.features_static(color, lastp, scal, feat, legal, augs)
+        torch.cuda.synchronize()
+        if call == 1:
+            assert torch.cuda.mem_get_info(dev)[0] == free0, "the call changed the free device memory"
+        assert torch.equal(feat.view(torch.int32), want_f.view(torch.int32)), "planes differ on call %d" % call
+        assert torch.equal(legal, want_l), "legal masks differ on call %d" % call
+        # and against the oracle, on a sample of the rows
+        c, lp, sc = color.cpu().numpy(), lastp.cpu().numpy(), scal.cpu().numpy()
+        f, lg, ag = feat.cpu().numpy(), legal.cpu().numpy(), augs.cpu().tolist()
+        for b in range(0, n, 17):
+            o = OracleBoard()
+            o.set_state(c[b], lp[b], sc[b])
+            assert_planes_equal(f[b], o.extract(ag[b]), "call %d row %d" % (call, b))
+            assert np.array_equal(lg[b], o.legal())
+
+
+def test_static_entry_point_limits(goenv):
+    dev = torch.device("cuda", 0)
+    n = goenv.STATIC_MAX_BOARDS + 1
+    color = torch.zeros(n, 361, dtype=torch.uint8, device=dev)
+    scal = torch.zeros(n, 16, dtype=torch.int32, device=dev)
+    legal = torch.zeros(n, 361, dtype=torch.uint8, device=dev)
+    with pytest.raises(goenv.GoEnvError, match="GOENV_STATIC_MAX_BOARDS"):
+        goenv.features_static(color, None, scal, None, legal)
+    with pytest.raises(goenv.GoEnvError, match="no output buffer"):
+        goenv.features_static(color[:4], None, scal[:4], None, None)
+    # the maximum itself works; empty boards: every point legal, last_placed optional
+    n = goenv.STATIC_MAX_BOARDS
+    scal[:, 0] = 1
+    scal[:, 1] = 1
+    scal[:, 9] = -1
+    goenv.features_static(color[:n], None, scal[:n], None, legal[:n])
+    torch.cuda.synchronize()
+    assert int(legal[:n].sum().item()) == n * 361
+    assert int(legal[n:].sum().item()) == 0
