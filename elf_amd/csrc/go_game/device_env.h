@@ -29,9 +29,11 @@ class DevBuf {
     release();
     chk(goenv_device_alloc(ctx, bytes, &p_), "goenv_device_alloc");
     cap_ = bytes;
+    ctx_ = ctx;
   }
+  // must run before the context it was allocated under is destroyed
   void release() {
-    if (p_) goenv_device_free(p_);
+    if (p_) goenv_device_free(ctx_, p_);
     p_ = nullptr;
     cap_ = 0;
   }
@@ -41,6 +43,7 @@ class DevBuf {
  private:
   void* p_ = nullptr;
   size_t cap_ = 0;
+  goenv_ctx* ctx_ = nullptr;
 };
 
 // The boards of one GameContext on one GPU.
@@ -60,9 +63,9 @@ class DeviceEnv {
   int n() const { return n_; }
   void set_stream(void* s) { stream_ = s; }
   void* stream() const { return stream_; }
-  void sync() { chk(goenv_sync(stream_), "goenv_sync"); }
-  void h2d(void* dst, const void* src, size_t bytes) { chk(goenv_copy(dst, src, bytes, stream_), "goenv_copy"); }
-  void d2h(void* dst, const void* src, size_t bytes) { chk(goenv_copy(dst, src, bytes, stream_), "goenv_copy"); }
+  void sync() { chk(goenv_sync(ctx_, stream_), "goenv_sync"); }
+  void h2d(void* dst, const void* src, size_t bytes) { chk(goenv_copy(ctx_, dst, src, bytes, stream_), "goenv_copy"); }
+  void d2h(void* dst, const void* src, size_t bytes) { chk(goenv_copy(ctx_, dst, src, bytes, stream_), "goenv_copy"); }
 
   // --- synchronous single-board operations (the offline loader's rare paths) ---------------
 

@@ -84,6 +84,8 @@ struct GameOptions {
                                    // restarts only on an illegal move, go/game.cc:81-90)
   bool signal_restart = false;     // selfplay: restart -> game_counter++, seq=0, last_terminal=1
                                    // (the reference's Go loop never calls AIComm::Restart there)
+  bool fuse_selfplay = true;       // selfplay with device tensors: Steps() = ONE launch that also writes the
+                                   // games' next samples (false: Wait() extracts them, as in round 1)
 };
 
 // elf/state_collector.h:112-143
@@ -160,8 +162,17 @@ struct Collector {
   std::vector<int> boards;     // their boards (row order)
   bool contiguous = false;     // boards are first, first+1, ...
   long batches = 0, samples = 0;
+  // selfplay with device tensors: Steps() already wrote the NEXT samples of `games` into the input
+  // tensors (one fused launch); the next Wait() only hands the batch out
+  bool prefilled = false;
+  uint64_t prefill_stamp = 0;
   // device staging
   DevBuf idx, aug, actions, status, stage_s, stage_legal, stage_meta[8], stage_pi;
+  void release_buffers() {
+    idx.release(); aug.release(); actions.release(); status.release(); stage_s.release(); stage_legal.release();
+    for (auto& m : stage_meta) m.release();
+    stage_pi.release();
+  }
 };
 
 struct SeqState {  // SeqInfo, elf/common.h:11-19
@@ -319,7 +330,7 @@ class GameContext {
         games_[g].requests.resize(co_.mcts_options.num_threads);
       }
     }
-    for (auto& g : groups_) g.ready.clear();
+    for (auto& g : groups_) { g.ready.clear(); g.stamp.clear(); }
     const uint64_t base_seed = opt_.seed ? (uint64_t)opt_.seed : clock_seed();
     for (int g = 0; g < co_.num_games; ++g) {
       GameSlot& gs = games_[g];
@@ -349,7 +360,8 @@ class GameContext {
     if (env_) {
       try { env_->sync(); } catch (...) {}
     }
-    for (auto& c : collectors_) { c->busy = false; c->games.clear(); }
+    for (auto& c : collectors_) { c->busy = false; c->prefilled = false; c->games.clear(); c->release_buffers(); }
+    for (DevBuf* b : {&ts_src_, &ts_dst_, &ts_act_, &ts_status_, &ts_topa_, &ts_topp_, &ts_v_}) b->release();
     games_.clear();
     searches_.clear();
     finished_.clear();
@@ -378,10 +390,16 @@ class GameContext {
     if (infos.gid < 0) return;  // timed-out Wait: nothing to release (comm_template.h:270)
     Collector& c = collector(infos.gid);
     if (!c.busy) throw std::range_error("Steps(): collector " + std::to_string(infos.gid) + " has no batch outstanding");
+    bool fused = false;
     if (offline_) steps_offline(c);
     else if (leaf_batch(c)) steps_mcts(c);
-    else steps_play(c);
+    else fused = steps_play(c);
     c.busy = false;
+    if (fused) {  // the games stay with the collector: their next samples are in its tensors already
+      c.prefilled = true;
+      c.prefill_stamp = ++clock_;
+      return;
+    }
     if (!leaf_batch(c))
       for (int ticket : c.games) produce_sample(ticket / tick_);
     c.games.clear();
@@ -469,6 +487,7 @@ class GameContext {
     std::string name;
     std::vector<int> members;
     std::deque<int> ready;
+    std::deque<uint64_t> stamp;   // when each ready ticket was queued (order among prefilled batches)
     size_t rr = 0;
   };
 
@@ -483,6 +502,7 @@ class GameContext {
   std::vector<Group> groups_;
   std::vector<GameSlot> games_;
   size_t rr_group_ = 0;
+  uint64_t clock_ = 0;          // orders queued games and prefilled batches: the oldest is served first
   // tree search (use_mcts): a batch row is a ticket = game * tick_ + (0: the game's own sample,
   // 1 + t: the leaf of search thread t); without tree search tick_ = 1 and tickets are game ids
   bool mcts_ = false;
@@ -540,7 +560,12 @@ class GameContext {
     }
     const int e = group_of(sample_name(gs));
     if (e < 0) throw std::range_error("no collector takes samples named \"" + sample_name(gs) + "\"");
-    groups_[e].ready.push_back(g * tick_);
+    enqueue(e, g * tick_);
+  }
+
+  void enqueue(int e, int ticket) {
+    groups_[e].ready.push_back(ticket);
+    groups_[e].stamp.push_back(++clock_);
   }
 
   // lets the search threads of game g run until each waits for a leaf; queues those leaves
@@ -554,7 +579,7 @@ class GameContext {
     const int e = group_of("actor");
     for (const LeafRequest& r : rq) {
       games_[g].requests[r.thread] = r;
-      groups_[e].ready.push_back(g * tick_ + 1 + r.thread);
+      enqueue(e, g * tick_ + 1 + r.thread);
     }
     if (searches_[g]->done()) finished_.push_back(g);
   }
@@ -606,15 +631,24 @@ class GameContext {
 
   Infos wait_impl(int only_gid) {
     if (!started_) throw std::range_error("Wait() before Start()");
-    // pick a free collector whose group has parked games; full batches first
+    // the oldest batch that Steps() has already filled (fused selfplay step), if any
+    Collector* pre = nullptr;
+    for (auto& cp : collectors_) {
+      Collector& c = *cp;
+      if (!c.prefilled || (only_gid >= 0 && c.gid != only_gid)) continue;
+      if (!pre || c.prefill_stamp < pre->prefill_stamp) pre = &c;
+    }
+    // a free collector whose group has parked games; full batches first, a short batch only when
+    // nothing else can progress
     Collector* pick = nullptr;
     for (int pass = 0; pass < 2 && !pick; ++pass) {
+      if (pass == 1 && pre) break;
       for (size_t k = 0; k < groups_.size() && !pick; ++k) {
         Group& grp = groups_[(rr_group_ + k) % groups_.size()];
         if (grp.ready.empty()) continue;
         for (size_t j = 0; j < grp.members.size(); ++j) {
           Collector& c = *collectors_[grp.members[(grp.rr + j) % grp.members.size()]];
-          if (c.busy || (only_gid >= 0 && c.gid != only_gid)) continue;
+          if (c.busy || c.prefilled || (only_gid >= 0 && c.gid != only_gid)) continue;
           if (pass == 0 && (int)grp.ready.size() < c.batchsize) continue;
           pick = &c;
           grp.rr = (grp.rr + j + 1) % grp.members.size();
@@ -623,6 +657,16 @@ class GameContext {
       }
     }
     Infos infos;
+    if (pre && (!pick || pre->prefill_stamp < groups_[pick->exclusive_id].stamp.front())) {
+      Collector& c = *pre;
+      c.prefilled = false;
+      c.busy = true;
+      c.batches += 1;
+      c.samples += (long)c.games.size();
+      infos.gid = c.gid;
+      infos.s = c.games;
+      return infos;
+    }
     if (!pick) return infos;  // gid = -1, as a timed-out wait (elf/state_collector.h:91)
     rr_group_ = (rr_group_ + 1) % groups_.size();
     Collector& c = *pick;
@@ -630,6 +674,7 @@ class GameContext {
     const int n = std::min<int>(c.batchsize, (int)grp.ready.size());
     c.games.assign(grp.ready.begin(), grp.ready.begin() + n);
     grp.ready.erase(grp.ready.begin(), grp.ready.begin() + n);
+    grp.stamp.erase(grp.stamp.begin(), grp.stamp.begin() + n);
     fill_inputs(c);
     c.busy = true;
     c.batches += 1;
@@ -792,28 +837,57 @@ class GameContext {
 
   // selfplay / online: DirectPredictAI::handle_response + GoState::forward, restart on an
   // illegal move (go/go_ai.h:89-93, go/game.cc:80-93)
-  void steps_play(Collector& c) {
+  // Returns true when the step was FUSED: one launch sampled / took the moves, applied them and wrote
+  // the games' next samples into this collector's input tensors (the batch is then `prefilled`).
+  bool steps_play(Collector& c) {
     const int n = (int)c.games.size();
     const int32_t* d_idx = c.contiguous ? nullptr : c.idx.as<int32_t>();
     const int first = c.contiguous ? c.boards[0] : 0;
-    const int64_t* d_a = (const int64_t*)reply_ptr(c, "a", c.actions, (size_t)n * 8);
-    if (!d_a) {
-      // the reference reads an unwritten GameState::a here (SURVEY 3.1 note ii); this build
-      // samples the move from the policy head over the legal points instead
-      const float* d_pi = (const float*)reply_ptr(c, "pi", c.stage_pi, (size_t)n * GOENV_NUM_POINTS * 4);
-      if (!d_pi) throw std::range_error("Steps(): the reply of collector " + std::to_string(c.gid) +
-                                        " carries neither \"a\" nor \"pi\"");
-      c.actions.ensure(env_->ctx(), (size_t)n * 8);
-      chk(goenv_sample_policy(env_->ctx(), d_idx, first, n, d_pi, nullptr, c.actions.as<int64_t>(), env_->stream()),
-          "goenv_sample_policy");
-      d_a = c.actions.as<int64_t>();
-    }
     const bool online = opt_.mode == "online";
     uint32_t flags = 0;
     int human = 0;
     for (int ticket : c.games) human += games_[ticket / tick_].phase == 0;
     if (!(online && human)) flags |= GOENV_F_RESET_ILLEGAL;  // a human's illegal move is asked again
     if (opt_.end_on_two_passes || opt_.ply_cap > 0) flags |= GOENV_F_RESTART_AFTER_END;
+    const int64_t* d_a = (const int64_t*)reply_ptr(c, "a", c.actions, (size_t)n * 8);
+    const float* d_pi = nullptr;
+    if (!d_a) {
+      // the reference reads an unwritten GameState::a here (SURVEY 3.1 note ii); this build
+      // samples the move from the policy head over the legal points instead
+      d_pi = (const float*)reply_ptr(c, "pi", c.stage_pi, (size_t)n * GOENV_NUM_POINTS * 4);
+      if (!d_pi) throw std::range_error("Steps(): the reply of collector " + std::to_string(c.gid) +
+                                        " carries neither \"a\" nor \"pi\"");
+    }
+    if (can_fuse(c)) {
+      goenv_sample_out so;
+      std::memset(&so, 0, sizeof(so));
+      so.mode = opt_.signal_restart ? GOENV_SEQ_EPISODES : GOENV_SEQ_RUN_ON;
+      void** fields[8] = {(void**)&so.id, (void**)&so.seq, (void**)&so.game_counter, (void**)&so.last_terminal,
+                          (void**)&so.move_idx, (void**)&so.winner, (void**)&so.aug_code, (void**)&so.game_record_idx};
+      for (int k = 0; k < 8; ++k) {
+        auto it = c.input.find(kMetaKeys[k]);
+        *fields[k] = it == c.input.end() ? nullptr : it->second.p;
+      }
+      auto dev_in = [&](const char* key) -> void* {
+        auto it = c.input.find(key);
+        return it == c.input.end() ? nullptr : it->second.p;
+      };
+      float* d_s = (float*)dev_in("s");
+      uint8_t* d_l = (uint8_t*)dev_in("legal");
+      if (d_a)
+        chk(goenv_ply_sel(env_->ctx(), d_idx, first, n, flags | GOENV_F_COLLECT, d_a, nullptr, d_s, d_l, &so, nullptr,
+                          nullptr, env_->stream()), "goenv_ply_sel");
+      else
+        chk(goenv_ply_policy_sel(env_->ctx(), d_idx, first, n, flags | GOENV_F_COLLECT, d_pi, nullptr, nullptr, d_s, d_l,
+                                 &so, nullptr, nullptr, env_->stream()), "goenv_ply_policy_sel");
+      return true;
+    }
+    if (!d_a) {
+      c.actions.ensure(env_->ctx(), (size_t)n * 8);
+      chk(goenv_sample_policy(env_->ctx(), d_idx, first, n, d_pi, nullptr, c.actions.as<int64_t>(), env_->stream()),
+          "goenv_sample_policy");
+      d_a = c.actions.as<int64_t>();
+    }
     int32_t* d_status = nullptr;
     if (online) {
       c.status.ensure(env_->ctx(), (size_t)n * 4);
@@ -837,6 +911,23 @@ class GameContext {
         }
       }
     }
+    return false;
+  }
+
+  // A selfplay step may be fused when the device keeps the sequencing (plain selfplay), every
+  // registered input tensor is device memory (the kernel writes them in place), and no parked game
+  // could starve: the group's queue is empty, or another collector of the group stays free for it.
+  bool can_fuse(const Collector& c) const {
+    if (!opt_.fuse_selfplay || offline_ || mcts_ || opt_.mode != "selfplay") return false;
+    for (const auto& kv : c.input)
+      if (!kv.second.device) return false;
+    const Group& grp = groups_[c.exclusive_id];
+    if (grp.ready.empty()) return true;
+    for (int gid : grp.members) {
+      const Collector& o = *collectors_[gid];
+      if (o.gid != c.gid && !o.busy && !o.prefilled) return true;
+    }
+    return false;
   }
 
   // tree search: the replies (pi, V) of a batch of leaves.  DirectPredictAI::get_last_pi keeps the
@@ -964,7 +1055,8 @@ PYBIND11_MODULE(go_game, m) {
       .def_readwrite("komi", &GameOptions::komi)
       .def_readwrite("ply_cap", &GameOptions::ply_cap)
       .def_readwrite("end_on_two_passes", &GameOptions::end_on_two_passes)
-      .def_readwrite("signal_restart", &GameOptions::signal_restart);
+      .def_readwrite("signal_restart", &GameOptions::signal_restart)
+      .def_readwrite("fuse_selfplay", &GameOptions::fuse_selfplay);
 
   py::class_<EntryInfo>(m, "EntryInfo")
       .def(py::init<>())

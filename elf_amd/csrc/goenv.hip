@@ -33,6 +33,8 @@ struct PlyParams {
   goenv_sample_out meta;
   uint32_t flags;
   const int64_t* actions;
+  const float* pi;         // MODE 2: policy weights [n][361], row b in the frame of pi_aug[b]
+  const int32_t* pi_aug;
   const int32_t* aug;
   float* feat;
   uint8_t* legal;
@@ -135,6 +137,53 @@ __device__ __forceinline__ void emit_sample_meta(const goenv_sample_out& o, int 
   s.seqtot += 1;
 }
 
+// Move selection from a policy head: sample p proportional to pi[p] over the LEGAL points, in exact
+// integer arithmetic (weights floor(pi * 2^24)), keyed by the counter RNG; all-zero weights fall
+// back to the cfg-2 random policy.  `row` is indexed in the augmented frame `aug`.  Works on the
+// uniform six-word masks, so every wave of a board computes the same result by itself.
+__device__ __forceinline__ int pick_policy_move(const Masks& m, int lane, const Scalars& s, const float* __restrict__ row,
+                                                int aug, uint64_t seed, uint64_t board_id) {
+  uint32_t pre[NWORDS], sum[NWORDS];
+  unsigned long long total = 0;
+  GO_UNROLL
+  for (int k = 0; k < NWORDS; ++k) {
+    const int p = lane + 64 * k;
+    uint32_t w = 0;
+    if (p < NPTS && ((m.legal[k] >> lane) & 1ull)) {
+      const float f = row[aug ? d4_dest(aug, p) : p];
+      if (f > 0.f) {
+        const float sc = f * 16777216.0f;
+        w = sc >= 16777216.0f ? 16777216u : (uint32_t)sc;
+      }
+    }
+    uint32_t v = w;
+    GO_UNROLL
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(v, d);
+      if (lane >= d) v += t;
+    }
+    pre[k] = v;
+    sum[k] = __shfl(v, 63);
+    total += sum[k];
+  }
+  if (total == 0) return pick_random_move(m, lane, s, seed, board_id);
+  const uint64_t u = policy_rand(seed ^ 0xA5A5A5A55A5A5A5Aull, board_id, (uint64_t)s.game, (uint64_t)s.ply);
+  unsigned long long r = u % total;
+  int a = -1;
+  GO_UNROLL
+  for (int k = 0; k < NWORDS; ++k) {
+    if (a < 0) {
+      if (r < sum[k]) {
+        const unsigned long long hit = __ballot((unsigned long long)pre[k] > r);
+        a = 64 * k + (int)__builtin_ctzll(hit);
+      } else {
+        r -= sum[k];
+      }
+    }
+  }
+  return a;
+}
+
 // One ply for one board held in LDS/registers.  `m` = masks of the position (all words), `o`
 // receives this wave's words of the NEW position's masks.  Returns the action applied (-1 pass)
 // or -4 if the external action was illegal (state and `o` untouched).
@@ -175,8 +224,12 @@ __device__ __forceinline__ int ply_body(BoardLds<NW>& L, const Geo<NW>& g, uint3
   return a;
 }
 
-template <int NW, bool RANDOM>
+// MODE 0: the move is actions[b]; 1: the on-device cfg-2 policy; 2: sampled from pi[b] over the legal
+// points (pick_policy_move), after any restart of a finished board, so one launch is a whole
+// selfplay step: reply -> move -> rules -> next sample's mask, planes and sequencing record.
+template <int NW, int MODE>
 __global__ __launch_bounds__(64 * NW) void k_ply(PlyParams P) {
+  constexpr bool RANDOM = MODE == 1;
   __shared__ BoardLds<NW> L;
   if ((int)blockIdx.x >= P.n) return;
   const int b = xcd_row(blockIdx.x, P.n, P.xcd_map);
@@ -210,11 +263,12 @@ __global__ __launch_bounds__(64 * NW) void k_ply(PlyParams P) {
   }
   STAMP(1);
 
-  bool skip = false;
+  bool skip = false, restarted = false;
   if (s.done) {
     if (P.flags & GOENV_F_AUTO_RESTART) {
       if (!s.counted) account_game(P.stats, g.tid, s, tromp_taylor(L, g, lab), P.komi);
       restart_in_place(L, g, lab, lastp, s, m, o);
+      restarted = true;  // the record must be stored even if the move is then rejected
     } else if (P.flags & GOENV_F_SKIP_DONE) {
       skip = true;
     }
@@ -223,7 +277,14 @@ __global__ __launch_bounds__(64 * NW) void k_ply(PlyParams P) {
   if (!skip) {
     // the masks of the new position are computed AFTER the planes have been issued: the plane
     // stores then drain to HBM while the workgroup finishes its mask / record tail
-    a = ply_body<NW, RANDOM, false>(L, g, lab, lastp, s, m, o, P, board, RANDOM ? 0ll : (long long)P.actions[b]);
+    long long av = 0;
+    if (MODE == 0) av = (long long)P.actions[b];
+    if (MODE == 2) {
+      const int pa = P.pi_aug ? (P.pi_aug[b] & 7) : 0;
+      av = __builtin_amdgcn_readfirstlane(
+          pick_policy_move(m, g.lane, s, P.pi + (size_t)b * NPTS, pa, P.seed, (uint64_t)(P.id_base + board)));
+    }
+    a = ply_body<NW, RANDOM, false>(L, g, lab, lastp, s, m, o, P, board, av);
     status = (a == -4) ? 0 : 1;
     bool fresh = false;  // restarted: `o` already holds the masks of the empty board
     if (a == -4 && (P.flags & GOENV_F_RESET_ILLEGAL)) {
@@ -260,7 +321,7 @@ __global__ __launch_bounds__(64 * NW) void k_ply(PlyParams P) {
 #endif
     STAMP(6);
 #ifndef GOENV_ABLATE_RECSTORE
-    if (a != -4 || (P.flags & (GOENV_F_RESET_ILLEGAL | GOENV_F_COLLECT)))
+    if (a != -4 || restarted || (P.flags & (GOENV_F_RESET_ILLEGAL | GOENV_F_COLLECT)))
       store_board(rec, g, lab, lastp, o, s);
 #endif
   }
@@ -343,50 +404,7 @@ __global__ __launch_bounds__(64) void k_sample_policy(const BoardRec* state, int
   Masks m;
   load_masks(rec, m);
   const int aug = aug_codes ? (aug_codes[b] & 7) : 0;
-  const float* row = pi + (size_t)b * NPTS;
-  uint32_t pre[NWORDS], sum[NWORDS];
-  unsigned long long total = 0;
-  GO_UNROLL
-  for (int k = 0; k < NWORDS; ++k) {
-    const int p = lane + 64 * k;
-    uint32_t w = 0;
-    if (p < NPTS && ((m.legal[k] >> lane) & 1ull)) {
-      const float f = row[aug ? d4_dest(aug, p) : p];
-      if (f > 0.f) {
-        const float sc = f * 16777216.0f;
-        w = sc >= 16777216.0f ? 16777216u : (uint32_t)sc;
-      }
-    }
-    uint32_t v = w;
-    GO_UNROLL
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t t = __shfl_up(v, d);
-      if (lane >= d) v += t;
-    }
-    pre[k] = v;
-    sum[k] = __shfl(v, 63);
-    total += sum[k];
-  }
-  int a;
-  if (total == 0) {
-    a = pick_random_move(m, lane, s, seed, (uint64_t)(id_base + board));
-  } else {
-    const uint64_t u = policy_rand(seed ^ 0xA5A5A5A55A5A5A5Aull, (uint64_t)(id_base + board), (uint64_t)s.game,
-                                   (uint64_t)s.ply);
-    unsigned long long r = u % total;
-    a = -1;
-    GO_UNROLL
-    for (int k = 0; k < NWORDS; ++k) {
-      if (a < 0) {
-        if (r < sum[k]) {
-          const unsigned long long hit = __ballot((unsigned long long)pre[k] > r);
-          a = 64 * k + (int)__builtin_ctzll(hit);
-        } else {
-          r -= sum[k];
-        }
-      }
-    }
-  }
+  const int a = pick_policy_move(m, lane, s, pi + (size_t)b * NPTS, aug, seed, (uint64_t)(id_base + board));
   if (lane == 0) actions_out[b] = a;
 }
 
@@ -786,23 +804,22 @@ __global__ __launch_bounds__(64) void k_tactics(const BoardRec* state, int n_tot
     }                                                                                                \
   } while (0)
 
-#define GO_LAUNCH_PLY(NWSEL, RANDOM, GRID, STREAM, P)                                                      \
-  do {                                                                                                    \
-    if (RANDOM) {                                                                                         \
-      switch (NWSEL) {                                                                                    \
-        case 2: hipLaunchKernelGGL((k_ply<2, true>), dim3(GRID), dim3(128), 0, STREAM, P); break;         \
-        case 3: hipLaunchKernelGGL((k_ply<3, true>), dim3(GRID), dim3(192), 0, STREAM, P); break;         \
-        case 6: hipLaunchKernelGGL((k_ply<6, true>), dim3(GRID), dim3(384), 0, STREAM, P); break;         \
-        default: hipLaunchKernelGGL((k_ply<1, true>), dim3(GRID), dim3(64), 0, STREAM, P); break;         \
-      }                                                                                                   \
-    } else {                                                                                              \
-      switch (NWSEL) {                                                                                    \
-        case 2: hipLaunchKernelGGL((k_ply<2, false>), dim3(GRID), dim3(128), 0, STREAM, P); break;        \
-        case 3: hipLaunchKernelGGL((k_ply<3, false>), dim3(GRID), dim3(192), 0, STREAM, P); break;        \
-        case 6: hipLaunchKernelGGL((k_ply<6, false>), dim3(GRID), dim3(384), 0, STREAM, P); break;        \
-        default: hipLaunchKernelGGL((k_ply<1, false>), dim3(GRID), dim3(64), 0, STREAM, P); break;        \
-      }                                                                                                   \
-    }                                                                                                     \
+#define GO_LAUNCH_PLY_MODE(NWSEL, MODE, GRID, STREAM, P)                                              \
+  do {                                                                                                \
+    switch (NWSEL) {                                                                                  \
+      case 2: hipLaunchKernelGGL((k_ply<2, MODE>), dim3(GRID), dim3(128), 0, STREAM, P); break;       \
+      case 3: hipLaunchKernelGGL((k_ply<3, MODE>), dim3(GRID), dim3(192), 0, STREAM, P); break;       \
+      case 6: hipLaunchKernelGGL((k_ply<6, MODE>), dim3(GRID), dim3(384), 0, STREAM, P); break;       \
+      default: hipLaunchKernelGGL((k_ply<1, MODE>), dim3(GRID), dim3(64), 0, STREAM, P); break;       \
+    }                                                                                                 \
+  } while (0)
+
+// MODESEL: 0 external actions, 1 on-device random policy, 2 sampled from pi
+#define GO_LAUNCH_PLY(NWSEL, MODESEL, GRID, STREAM, P)                  \
+  do {                                                                  \
+    if ((MODESEL) == 1) GO_LAUNCH_PLY_MODE(NWSEL, 1, GRID, STREAM, P);  \
+    else if ((MODESEL) == 2) GO_LAUNCH_PLY_MODE(NWSEL, 2, GRID, STREAM, P); \
+    else GO_LAUNCH_PLY_MODE(NWSEL, 0, GRID, STREAM, P);                 \
   } while (0)
 
 // ----------------------------------------------------------------------------------------------
@@ -903,7 +920,7 @@ struct DeviceScope {
 
 extern "C" {
 
-int goenv_version(void) { return 1; }
+int goenv_version(void) { return 2; }
 
 const char* goenv_last_error(void) { return g_err.c_str(); }
 
@@ -1041,22 +1058,40 @@ static int check_sel(goenv_ctx* c, const int32_t* idx, int first, int count, con
   return 0;
 }
 
-int goenv_ply_sel(goenv_ctx* c, const int32_t* idx, int first, int count, uint32_t flags, const int64_t* actions,
-                  const int32_t* aug_codes, float* feat_out, uint8_t* legal_out, const goenv_sample_out* meta,
-                  int32_t* actions_out, int32_t* status_out, void* stream) {
-  if (check_sel(c, idx, first, count, "goenv_ply_sel")) return -1;
+static int ply_sel_impl(goenv_ctx* c, const char* who, const int32_t* idx, int first, int count, uint32_t flags,
+                        const int64_t* actions, const float* pi, const int32_t* pi_aug, const int32_t* aug_codes,
+                        float* feat_out, uint8_t* legal_out, const goenv_sample_out* meta, int32_t* actions_out,
+                        int32_t* status_out, void* stream) {
+  if (check_sel(c, idx, first, count, who)) return -1;
   ON_DEVICE_OF(c);
-  const bool random = flags & GOENV_F_RANDOM_POLICY;
-  if (!random && !actions) return fail("goenv_ply: actions required unless GOENV_F_RANDOM_POLICY is set");
+  const int mode = pi ? 2 : ((flags & GOENV_F_RANDOM_POLICY) ? 1 : 0);
+  if (mode == 0 && !actions) return fail("goenv_ply: actions required unless GOENV_F_RANDOM_POLICY is set");
   if ((flags & GOENV_F_COLLECT) && !meta) return fail("goenv_ply: GOENV_F_COLLECT needs a goenv_sample_out");
   if (count == 0) return 0;
   PlyParams P = make_params(c, flags, actions, aug_codes, feat_out, legal_out, actions_out, status_out);
   P.n = count; P.idx = idx; P.first = first;
+  P.pi = pi; P.pi_aug = pi_aug;
   P.zero_first = pick_zero_first(c, count);
   if (meta) P.meta = *meta;
-  GO_LAUNCH_PLY(pick_nw(c, count), random, count, S(stream), P);
+  GO_LAUNCH_PLY(pick_nw(c, count), mode, count, S(stream), P);
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+int goenv_ply_sel(goenv_ctx* c, const int32_t* idx, int first, int count, uint32_t flags, const int64_t* actions,
+                  const int32_t* aug_codes, float* feat_out, uint8_t* legal_out, const goenv_sample_out* meta,
+                  int32_t* actions_out, int32_t* status_out, void* stream) {
+  return ply_sel_impl(c, "goenv_ply_sel", idx, first, count, flags, actions, nullptr, nullptr, aug_codes, feat_out,
+                      legal_out, meta, actions_out, status_out, stream);
+}
+
+int goenv_ply_policy_sel(goenv_ctx* c, const int32_t* idx, int first, int count, uint32_t flags, const float* pi,
+                         const int32_t* pi_aug_codes, const int32_t* aug_codes, float* feat_out, uint8_t* legal_out,
+                         const goenv_sample_out* meta, int32_t* actions_out, int32_t* status_out, void* stream) {
+  if (!pi) return fail("goenv_ply_policy_sel: pi is required");
+  if (flags & GOENV_F_RANDOM_POLICY) return fail("goenv_ply_policy_sel: GOENV_F_RANDOM_POLICY does not apply");
+  return ply_sel_impl(c, "goenv_ply_policy_sel", idx, first, count, flags, nullptr, pi, pi_aug_codes, aug_codes,
+                      feat_out, legal_out, meta, actions_out, status_out, stream);
 }
 
 int goenv_ply(goenv_ctx* c, uint32_t flags, const int64_t* actions, const int32_t* aug_codes, float* feat_out,
@@ -1135,7 +1170,7 @@ extern "C" int goenv_diag_ply(goenv_ctx* c, uint32_t flags, float* feat_out, uin
                               unsigned long long* stamps, void* stream) {
   PlyParams P = make_params(c, flags | GOENV_F_RANDOM_POLICY, nullptr, nullptr, feat_out, legal_out, nullptr, nullptr);
   P.stamps = stamps;
-  GO_LAUNCH_PLY(pick_nw(c, c->n), true, c->n, S(stream), P);
+  GO_LAUNCH_PLY(pick_nw(c, c->n), 1, c->n, S(stream), P);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1266,12 +1301,18 @@ int goenv_pointer_is_device(const void* p) {
   return attr.type == hipMemoryTypeDevice ? 1 : 0;
 }
 
-int goenv_copy(void* dst, const void* src, size_t bytes, void* stream) {
+// Both run with the context's device current: `stream` (NULL included: every device has a null stream
+// of its own) must be the stream the context's kernels were launched on, or nothing orders the two.
+int goenv_copy(goenv_ctx* c, void* dst, const void* src, size_t bytes, void* stream) {
+  if (!c) return fail("goenv_copy: ctx is NULL");
+  ON_DEVICE_OF(c);
   HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, S(stream)));
   return 0;
 }
 
-int goenv_sync(void* stream) {
+int goenv_sync(goenv_ctx* c, void* stream) {
+  if (!c) return fail("goenv_sync: ctx is NULL");
+  ON_DEVICE_OF(c);
   HIPCHK(hipStreamSynchronize(S(stream)));
   return 0;
 }
@@ -1283,7 +1324,9 @@ int goenv_device_alloc(goenv_ctx* c, size_t bytes, void** out) {
   return 0;
 }
 
-int goenv_device_free(void* p) {
+int goenv_device_free(goenv_ctx* c, void* p) {
+  if (!c) return fail("goenv_device_free: ctx is NULL");
+  ON_DEVICE_OF(c);
   if (p) HIPCHK(hipFree(p));
   return 0;
 }

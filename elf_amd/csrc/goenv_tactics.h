@@ -83,8 +83,10 @@ __device__ __forceinline__ int ladder_search(BoardLds<1>& L, TacticsLds& X, cons
   constexpr int K = Geo<1>::K;
   uint32_t dummy[K];
   int num_call = 0, depth = 1, sp = 0;
-  for (;;) {  // every iteration plays one stone or ends the search: bounded by the board
-    ++num_call;
+  for (;;) {  // every iteration plays one stone or ends the search
+    // hard bound every wave reaches: captures can re-open points, so the board alone does not bound
+    // the line; past 4 x 361 stones the search is abandoned with the same code as a full stack
+    if (++num_call > 4 * NPTS) return -1;
     const int c = s.l1, c2 = s.l2;
     const uint32_t lib = cls_of(__builtin_amdgcn_readfirstlane((uint32_t)L.lab[pad_of(c)]));
     int mv = -1;        // the stone to play on this path, -1 = this path fails

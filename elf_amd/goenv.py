@@ -32,7 +32,7 @@ S_PLY, S_NEXT, S_BCAP, S_WCAP, S_LAST1, S_LAST2, S_LAST3, S_LAST4, S_KO_AGE, S_K
 S_SEQ = 14
 # stats slots
 (ST_GAMES, ST_BLACK_WINS, ST_WHITE_WINS, ST_DRAWS, ST_PLIES, ST_BCAP, ST_WCAP, ST_SUM_LEN2, ST_PLY_CAP_HITS,
- ST_MAX_LEN, ST_SUM_SCORE, ST_MOVES_APPLIED, ST_ILLEGAL) = range(13)
+ ST_MAX_LEN, ST_SUM_SCORE) = range(11)
 
 _lib = None
 
@@ -54,6 +54,7 @@ _SIGS = {
     "goenv_ply_repeat": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32] + [C.c_void_p] * 6 + [C.c_void_p]),
     "goenv_ply_repeat_parts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32] + [C.c_void_p] * 6 + [C.c_void_p]),
     "goenv_ply_sel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32] + [C.c_void_p] * 8),
+    "goenv_ply_policy_sel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32] + [C.c_void_p] * 9),
     "goenv_collect_sel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5),
     "goenv_sample_policy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4),
     "goenv_get_state_sel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]),
@@ -63,10 +64,10 @@ _SIGS = {
     "goenv_host_free": (C.c_int, [C.c_void_p]),
     "goenv_copy_boards": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "goenv_pointer_is_device": (C.c_int, [C.c_void_p]),
-    "goenv_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "goenv_sync": (C.c_int, [C.c_void_p]),
+    "goenv_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "goenv_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "goenv_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
-    "goenv_device_free": (C.c_int, [C.c_void_p]),
+    "goenv_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "goenv_playout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "goenv_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goenv_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -121,12 +122,16 @@ class SampleOut(C.Structure):
                   move_idx=torch.int32, winner=torch.int32, aug_code=torch.int32, game_record_idx=torch.int32)
 
     @classmethod
-    def from_tensors(cls, tensors, mode=0):
+    def from_tensors(cls, tensors, mode=0, count=None, device=None):
         o = cls()
         o.mode = mode
         for k, t in tensors.items():
             if t.dtype != cls.DTYPES[k] or not t.is_contiguous():
                 raise GoEnvError("sample field %s must be a contiguous %s tensor" % (k, cls.DTYPES[k]))
+            if count is not None and t.numel() < count:
+                raise GoEnvError("sample field %s holds %d rows, the call writes %d" % (k, t.numel(), count))
+            if device is not None and t.device != device:
+                raise GoEnvError("sample field %s is on %s, the boards are on %s" % (k, t.device, device))
             setattr(o, k, t.data_ptr())
         return o
 
@@ -171,6 +176,16 @@ class GoEnv:
         if t.device != self.device or t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
             raise GoEnvError("%s must be a contiguous %s tensor of shape %s on %s (got %s %s on %s)" % (
                 name, dtype, tuple(shape), self.device, t.dtype, tuple(t.shape), t.device))
+
+    def _check_rows(self, count, aug_codes=None, feat_out=None, legal_out=None, actions_out=None, status_out=None,
+                    actions=None):
+        """Batch arrays of a selection call: one row per selected board."""
+        self._check(actions, torch.int64, (count,), "actions")
+        self._check(aug_codes, torch.int32, (count,), "aug_codes")
+        self._check(feat_out, torch.float32, (count, NUM_PLANES, 19, 19), "feat_out")
+        self._check(legal_out, torch.uint8, (count, NUM_POINTS), "legal_out")
+        self._check(actions_out, torch.int32, (count,), "actions_out")
+        self._check(status_out, torch.int32, (count,), "status_out")
 
     def close(self):
         if self._h:
@@ -284,19 +299,37 @@ class GoEnv:
                 legal_out=None, meta=None, actions_out=None, status_out=None):
         """goenv_ply_sel: batch arrays are indexed by the selection row."""
         ip, first, count = self._sel(idx, first, count)
-        m = SampleOut.from_tensors(meta) if meta is not None else None
+        self._check_rows(count, aug_codes, feat_out, legal_out, actions_out, status_out, actions)
+        m = SampleOut.from_tensors(meta, count=count, device=self.device) if meta is not None else None
         self._chk(self.lib.goenv_ply_sel(self._h, ip, first, count, flags, _ptr(actions), _ptr(aug_codes),
                                          _ptr(feat_out), _ptr(legal_out), C.byref(m) if m is not None else None,
                                          _ptr(actions_out), _ptr(status_out), self._stream()))
 
+    def ply_policy_sel(self, pi, idx=None, first=0, count=None, flags=0, pi_aug_codes=None, aug_codes=None,
+                       feat_out=None, legal_out=None, meta=None, actions_out=None, status_out=None):
+        """goenv_ply_policy_sel: sample from pi, apply, write the next sample -- one launch."""
+        ip, first, count = self._sel(idx, first, count)
+        self._check(pi, torch.float32, (count, NUM_POINTS), "pi")
+        self._check(pi_aug_codes, torch.int32, (count,), "pi_aug_codes")
+        self._check_rows(count, aug_codes, feat_out, legal_out, actions_out, status_out)
+        m = SampleOut.from_tensors(meta, count=count, device=self.device) if meta is not None else None
+        self._chk(self.lib.goenv_ply_policy_sel(self._h, ip, first, count, flags, _ptr(pi), _ptr(pi_aug_codes),
+                                                _ptr(aug_codes), _ptr(feat_out), _ptr(legal_out),
+                                                C.byref(m) if m is not None else None, _ptr(actions_out),
+                                                _ptr(status_out), self._stream()))
+
     def collect_sel(self, idx=None, first=0, count=None, aug_codes=None, feat_out=None, legal_out=None, meta=None):
         ip, first, count = self._sel(idx, first, count)
-        m = SampleOut.from_tensors(meta) if meta is not None else None
+        self._check_rows(count, aug_codes, feat_out, legal_out)
+        m = SampleOut.from_tensors(meta, count=count, device=self.device) if meta is not None else None
         self._chk(self.lib.goenv_collect_sel(self._h, ip, first, count, _ptr(aug_codes), _ptr(feat_out),
                                              _ptr(legal_out), C.byref(m) if m is not None else None, self._stream()))
 
     def sample_policy(self, pi, actions_out, idx=None, first=0, count=None, aug_codes=None):
         ip, first, count = self._sel(idx, first, count)
+        self._check(pi, torch.float32, (count, NUM_POINTS), "pi")
+        self._check(actions_out, torch.int64, (count,), "actions_out")
+        self._check(aug_codes, torch.int32, (count,), "aug_codes")
         self._chk(self.lib.goenv_sample_policy(self._h, ip, first, count, _ptr(pi), _ptr(aug_codes),
                                                _ptr(actions_out), self._stream()))
 

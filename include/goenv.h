@@ -84,9 +84,7 @@ enum {
   GOENV_ST_SUM_LEN2 = 7,
   GOENV_ST_PLY_CAP_HITS = 8,
   GOENV_ST_MAX_LEN = 9,
-  GOENV_ST_SUM_SCORE = 10,
-  GOENV_ST_MOVES_APPLIED = 11,
-  GOENV_ST_ILLEGAL = 12
+  GOENV_ST_SUM_SCORE = 10 /* slots 11..15 are reserved (zero) */
 };
 
 /* flags for goenv_ply */
@@ -269,6 +267,17 @@ int goenv_ply_sel(goenv_ctx* ctx, const int32_t* idx, int first, int count, uint
                   const int64_t* actions, const int32_t* aug_codes, float* feat_out,
                   uint8_t* legal_out, const goenv_sample_out* meta, int32_t* actions_out,
                   int32_t* status_out, void* stream);
+/* goenv_ply_policy_sel: a whole selfplay step of the selected boards in ONE launch -- what
+ * AIWithCommT::Act does around one reply (elf/ai.h:69-80) and GoGame::Act after it
+ * (go/game.cc:80-93): the move is sampled from the policy head `pi` over the legal points
+ * (as goenv_sample_policy; pi float32 [count][361], row b in the frame of pi_aug_codes[b],
+ * NULL = code 0), applied (flags as goenv_ply_sel: RESET_ILLEGAL, RESTART_AFTER_END, COLLECT ...),
+ * and the NEXT sample's planes (frame aug_codes), legal mask and sequencing record are written
+ * straight into the batch arrays.  actions_out int32 [count] receives the sampled move. */
+int goenv_ply_policy_sel(goenv_ctx* ctx, const int32_t* idx, int first, int count, uint32_t flags,
+                         const float* pi, const int32_t* pi_aug_codes, const int32_t* aug_codes,
+                         float* feat_out, uint8_t* legal_out, const goenv_sample_out* meta,
+                         int32_t* actions_out, int32_t* status_out, void* stream);
 int goenv_collect_sel(goenv_ctx* ctx, const int32_t* idx, int first, int count,
                       const int32_t* aug_codes, float* feat_out, uint8_t* legal_out,
                       const goenv_sample_out* meta, void* stream);
@@ -312,10 +321,12 @@ int goenv_copy_boards(goenv_ctx* ctx, const int32_t* src_idx, const int32_t* dst
  * device, SURVEY 8b "Ownership"), stream-ordered copy in either direction,
  * stream sync, staging allocation on the context's device. */
 int goenv_pointer_is_device(const void* p);
-int goenv_copy(void* dst, const void* src, size_t bytes, void* stream);
-int goenv_sync(void* stream);
+/* copy and sync run with the context's device current, on `stream` of THAT device (NULL = its null
+ * stream): pass the stream the context's launches use, so copies and kernels are ordered */
+int goenv_copy(goenv_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream);
+int goenv_sync(goenv_ctx* ctx, void* stream);
 int goenv_device_alloc(goenv_ctx* ctx, size_t bytes, void** out);
-int goenv_device_free(void* p);
+int goenv_device_free(goenv_ctx* ctx, void* p);
 /* pinned host staging memory (for small index / action / status arrays) */
 int goenv_host_alloc(size_t bytes, void** out);
 int goenv_host_free(void* p);
@@ -364,8 +375,8 @@ int goenv_fast_score(goenv_ctx* ctx, int rule, float* out, void* stream);
  *                                    order follows its stone list), else {-1, -1}
  *   ladder     int16 [count][361]    CheckLadder (go/board.cc:348-391, search :203-317) of a legal
  *                                    move: depth of the ladder it runs into, 0 = none; -1 = the
- *                                    search had more than 16 two-way branches pending at once and
- *                                    was abandoned (the reference recurses without that bound; on
+ *                                    search had more than 16 two-way branches pending at once, or
+ *                                    ran past 4 x 361 stones, and was abandoned (the reference recurses without that bound; on
  *                                    game records the maximum seen is 4)
  * Boards are not modified. */
 typedef struct goenv_tactics_out {

@@ -216,3 +216,76 @@ def test_gcwrapper_offline_training_batches(go):
         GC.Run()
     GC.Stop()
     assert len(seen) == 20 and GC.params["num_action"] == 361
+
+
+def _selfplay_context(go, N, B, ncoll, seed, fuse, keys, ply_cap=40):
+    co = go.ContextOptions()
+    co.num_games = N
+    opt = go.GameOptions()
+    opt.mode, opt.seed, opt.signal_restart, opt.end_on_two_passes, opt.ply_cap = "selfplay", seed, True, True, ply_cap
+    opt.fuse_selfplay = fuse
+    gc = go.GameContext(co, opt)
+    gs = gc.CreateGroupStat()
+    gs.name = "actor"
+    gids = [gc.AddCollectors(B, 0, 0, gs) for _ in range(ncoll)]
+    ins = [register(gc, gid, "input", keys, True) for gid in gids]
+    outs = [register(gc, gid, "reply", ["pi", "V"], True) for gid in gids]
+    gc.Start()
+    return gc, gids, ins, outs
+
+
+@pytest.mark.parametrize("N,B,ncoll", [(16, 16, 1), (16, 8, 2), (24, 8, 2), (10, 16, 1)])
+def test_fused_selfplay_step_against_oracle(go, N, B, ncoll):
+    """Selfplay with device tensors and a pi-only reply: Steps() is ONE launch (goenv_ply_policy_sel) that
+    samples the move, applies it and writes the games' next samples into the collector's tensors.  Every
+    sampled move is predicted by the oracle's sampler from the same pi, every delivered row (planes, mask,
+    sequencing record) is checked against an oracle board, and the whole stream equals the unfused path's
+    (Wait extracts, Steps samples + plies: three launches)."""
+    seed, cap = 13, 40
+    iters = 50 * -(-N // B)                                        # every game passes the ply cap at least once
+    keys = ["s", "legal"] + LABELS
+    streams = []
+    for fuse in (True, False):
+        gc, gids, ins, outs = _selfplay_context(go, N, B, ncoll, seed, fuse, keys, cap)
+        oracles = [OracleBoard() for _ in range(N)]
+        game = [0] * N
+        seq = [0] * N
+        fresh = [False] * N
+        served = [0] * N
+        rng = np.random.RandomState(5)
+        rows = []
+        for it in range(iters):
+            infos = gc.Wait(0)
+            k = gids.index(infos.gid)
+            n = len(infos.s)
+            assert n == min(B, N)
+            h = {key: v.cpu().numpy()[0] for key, v in ins[k].items()}
+            pi = rng.rand(n, 361).astype(np.float32)
+            pi[0] = 0.0                                           # all-zero row: the cfg-2 fallback policy
+            outs[k]["pi"][0, :n].copy_(torch.from_numpy(pi))
+            for r, g in enumerate(infos.s):
+                o = oracles[g]
+                assert h["id"][r] == g and h["seq"][r] == seq[g] and h["game_counter"][r] == game[g]
+                assert h["last_terminal"][r] == (1 if fresh[g] else 0)
+                assert h["move_idx"][r] == o.canonical()["scalars"][0]
+                assert np.array_equal(h["legal"][r], o.legal())
+                assert_planes_equal(h["s"][r], o.extract(0), "iter %d game %d" % (it, g))
+                rows.append((it, g, int(h["seq"][r]), fnv_planes(FNV_SEED, h["s"][r].reshape(-1))))
+                seq[g] += 1
+                fresh[g] = False
+                served[g] += 1
+                a = o.sample_policy(seed, g, game[g], pi[r], 0)
+                ok, end = o.forward(a)
+                assert ok
+                if end or o.canonical()["scalars"][0] > cap:      # scored, counted, restarted in place
+                    oracles[g] = OracleBoard()
+                    game[g] += 1
+                    seq[g] = 0
+                    fresh[g] = True
+            gc.Steps(infos)
+        assert max(served) - min(served) <= 1, "games are not served evenly: %s" % served
+        assert sum(game) > 0
+        assert gc.Stats()[0] >= sum(game)
+        gc.Stop()
+        streams.append(rows)
+    assert streams[0] == streams[1]
