@@ -19,7 +19,14 @@ Workload at N=1: BASELINE.json configs[1] -- 1,024 concurrent games, uniform-ran
 playouts to the end, 1 MI355X.  For N>1 every rank runs the same per-GPU batch (weak scaling),
 boards keyed by global id; the only collective is the end-of-run stats all-reduce (RCCL).
 
-    python bench.py --gpus N --steps K --warmup W [--boards B] [--ring R]
+Hygiene of the timed region (round 2): the boards are first rolled --preroll plies forward WITHOUT
+outputs (set-up, not warmup) so that they stand in the steady state of continuous selfplay -- games
+of every age, some ending, being scored and restarted inside any window; the warmup runs at least
+one full launch of the timed shape over the WHOLE ring, so no ring slot is first touched inside the
+timed region; the K-step region (barrier + synchronize on both sides) is then timed `reps` times
+back to back and the MEDIAN region is reported (ms_per_step x steps = one region).
+
+    python bench.py --gpus N --steps K --warmup W [--boards B] [--ring R] [--preroll P]
 """
 import argparse
 import json
@@ -44,37 +51,62 @@ ALG_BYTES_PER_BOARD_PLY = ALG_BYTES_PLANES + ALG_BYTES_LEGAL + ALG_BYTES_MOVE  #
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def cpu_share():
+    """(cores this process may use, logical CPUs of the host).  The share is the smallest of the
+    scheduler affinity, the cgroup CPU quota and the pool size the box exports (OMP_NUM_THREADS):
+    on the GPU box os.cpu_count() shows the whole machine, the job owns 16 of its CPUs."""
+    host = os.cpu_count() or 1
+    share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            share = min(share, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    try:
+        share = min(share, max(1, int(os.environ["OMP_NUM_THREADS"])))
+    except (KeyError, ValueError):
+        pass
+    return max(1, share), host
+
+
 def cpu_baseline(budget_sec=12.0):
     """The reference's own board.cc/board_feature.cc (oracle/_ref, kind "reference") -- or, when
     that build did not travel, our C port of it (kind "port") -- driving the same cfg-2 workload
-    with Extract on every ply, on this host's cores.  Bounded sample."""
+    with Extract on every ply, on every core this job owns.  Bounded sample."""
     from oracle.pyoracle import OracleBoard, RefBoard
-    threads = max(1, min(16, os.cpu_count() or 1))
+    threads, host = cpu_share()
     cls, kind = (RefBoard, "reference") if RefBoard.available() else (OracleBoard, "port")
     n_boards = threads * 4      # each thread plays games back to back until the budget is spent
     plies, sec = cls.bench_playouts(n_boards, threads, 1, 722, True, 1000000, budget_sec)
     plies_nf, sec_nf = cls.bench_playouts(n_boards, threads, 1, 722, False, 1000000, budget_sec / 3)
     return {
-        "value": plies / sec, "unit": "moves/s", "cores": threads, "kind": kind,
-        "sample": "cfg-2 policy playouts with BoardFeature::Extract on every ply, %d threads, "
-                  "%d plies in %.1f s (budget %.0f s)" % (threads, plies, sec, budget_sec),
+        "value": plies / sec, "unit": "moves/s", "cores": threads, "threads": threads, "host_logical_cpus": host,
+        "kind": kind,
+        "sample": "cfg-2 policy playouts with BoardFeature::Extract on every ply, one thread per core of this "
+                  "job's CPU share (%d of the host's %d logical CPUs), %d plies in %.1f s (budget %.0f s)"
+                  % (threads, host, plies, sec, budget_sec),
         "value_without_features": plies_nf / sec_nf,
     }
 
 
 def measured_traffic(boards, plies_per_launch):
-    """HBM bytes per launch of the generator kernel from the PMC passes of this round (FETCH_SIZE x2 +
-    WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes; collected by tools/profile_round.sh on
-    this same command and committed as profiles/r01_pmc.json), scaled to this run's plies per launch
-    (the kernel writes the same bytes for every ply).  None when no pass exists for this batch size."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
-            d = json.load(f)
-        if int(d["boards"]) != boards or "k_generate" not in d["kernel"]:
-            return None
-        return float(d["traffic_bytes"]) * plies_per_launch / float(d["plies_per_launch"])
-    except (OSError, ValueError, KeyError):
-        return None
+    """HBM bytes per launch of the generator kernel FROM THE COMMITTED PROFILE (not measured in this
+    run): FETCH_SIZE + WRITE_SIZE PMC passes over this same command, corrected as
+    MI355X_MICROARCH.md prescribes (tools/profile_round.sh -> profiles/rNN_pmc.json), scaled to this
+    run's plies per launch (the kernel writes the same bytes for every ply).  (None, None) when no
+    pass exists for this batch size."""
+    for name in ("r02_pmc.json", "r01_pmc.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            if int(d["boards"]) != boards or "k_generate" not in d["kernel"]:
+                continue
+            return float(d["traffic_bytes"]) * plies_per_launch / float(d["plies_per_launch"]), "profiles/" + name
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
 def plies_per_launch(steps, ring):
@@ -93,6 +125,9 @@ def main():
     ap.add_argument("--boards", type=int, default=1024, help="boards per GPU (cfg 2: 1024; cfg 4 shard: 8192)")
     ap.add_argument("--ring", type=int, default=64, help="ring depth in plies = most plies per generator launch")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--preroll", type=int, default=4096,
+                    help="plies every board is rolled forward without outputs before the warmup (set-up: steady state)")
+    ap.add_argument("--reps", type=int, default=0, help="timed regions (0 = as many as fit about 0.3 s, 1..15, odd)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -147,21 +182,43 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    steps(args.warmup, R)
-    sync()
-    env.timer_begin()
-    t0 = time.perf_counter()
-    steps(args.steps, T)
-    env.timer_end()
-    torch.cuda.synchronize()
+    # set-up: into the steady state of continuous selfplay (no outputs: a few ms), statistics restarted
+    done = 0
+    while done < args.preroll:
+        t = min(1024, args.preroll - done)
+        env.generate(t, None, None, None)
+        done += t
+    env.stats_clear()
+    # warmup: W plies, and at least one full launch of the timed shape over the whole ring
+    warm_plies = max(args.warmup, R)
+    steps(warm_plies, R)
     launches = -(-args.steps // T)
-    kernel_ms = env.timer_ms() / launches            # HIP events on the launch stream; average launch
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def region():
+        sync()
+        env.timer_begin()
+        t0 = time.perf_counter()
+        steps(args.steps, T)
+        env.timer_end()
+        env.timer_spin()                              # poll, do not sleep, until the last launch is done
+        torch.cuda.synchronize()
+        ms = env.timer_ms() / launches                # HIP events on the launch stream; average launch
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, ms
+
+    regions = [region()]
+    reps = args.reps if args.reps > 0 else max(1, min(15, int(0.3 / max(regions[0][0], 1e-6))))
+    reps |= 1                                          # odd: the median is one measured region
+    while len(regions) < reps:
+        regions.append(region())
+    regions.sort()
+    elapsed, kernel_ms = regions[len(regions) // 2]
+    kernel_ms = sorted(r[1] for r in regions)[len(regions) // 2]
 
     # end-of-episode statistics: count the games still in flight, then the one collective
     env.finish()
@@ -170,6 +227,7 @@ def main():
     value = world * B * args.steps / elapsed
     alg_launch = B * (args.steps / launches * ALG_BYTES_PER_BOARD_PLY + 2 * REC_BYTES)   # average launch
     achieved = alg_launch / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_src = measured_traffic(B, args.steps / launches)
     out = {
         "metric": "19x19 Go moves/sec (node, 1/2/4/8 GPU) + feature-extract HBM GB/s",
         "value": value, "unit": "moves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -181,10 +239,15 @@ def main():
                                "device ring buffers by the persistent generator (goenv_generate, %d plies per "
                                "launch)" % (B, T),
                    "boards_per_gpu": B, "global_boards": world * B, "ply_cap": 722,
-                   "plies_per_launch": args.steps / launches, "launches": launches, "parallelism": "shard%d" % world, "collective_backend": backend if world > 1 else None},
+                   "plies_per_launch": args.steps / launches, "launches": launches, "parallelism": "shard%d" % world,
+                   "collective_backend": backend if world > 1 else None,
+                   "preroll_plies": args.preroll, "warmup_plies_run": warm_plies, "reps": len(regions),
+                   "region_ms": [round(r[0] * 1e3, 4) for r in regions], "reported": "median region"},
         "roofline": {"bound": "hbm", "kernel": "k_generate", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B, args.steps / launches),
-                     "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc.md)",
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "frac_wall": alg_launch * launches / elapsed / 1e9 / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_unit": "bytes per launch, from %s (rocprofv3 PMC passes of this "
+                                                         "command; not measured in this run)" % traffic_src,
                      "algorithmic_bytes_per_launch": alg_launch,
                      "bytes_per_board_ply": ALG_BYTES_PER_BOARD_PLY, "record_bytes_per_board_launch": 2 * REC_BYTES,
                      "kernel_ms": kernel_ms},
@@ -256,6 +319,13 @@ def extra_measurements(goenv, seed):
     env.close()
     del fr, lr, ar
     torch.cuda.empty_cache()
+    # the API path the north star names: GameContext selfplay, Wait -> reply pi on the device -> Steps
+    for B in (1024, 8192):
+        res["game_context_selfplay_%d" % B] = game_context_selfplay(B, seed, True)
+        res["game_context_selfplay_%d" % B]["vs_launch_per_ply"] = (
+            res["game_context_selfplay_%d" % B]["moves_per_s"] / res["launch_per_ply_%d" % B]["moves_per_s"])
+        res["game_context_selfplay_%d" % B]["unfused_round1_path"] = game_context_selfplay(B, seed, False, steps=300)
+    res["cfg3_offline_256"] = cfg3_offline()
     env = goenv.GoEnv(1024, seed=seed, max_ply=722)
     nm = env.new(torch.int32)
     env.playout(None, nm)
@@ -269,6 +339,63 @@ def extra_measurements(goenv, seed):
                                       "moves_per_s": float(nm.sum().item()) / (ms * 1e-3)}
     env.close()
     return res
+
+
+def game_context_selfplay(B, seed, fuse, steps=1500, warm=100):
+    """GameContext in selfplay mode (elf_amd.go_game, the drop-in for the reference's pybind module):
+    B games, ONE collector of batch B, device tensors `s` + `legal` in, `pi` + `V` out; the reply is a
+    constant uniform pi already on the device (no model), so the number is the environment's own
+    API-level rate: Wait -> Steps, every Steps = sample a legal move from pi + rules + the next
+    batch's mask and 25 planes.  host_us_per_batch = time spent inside Wait() + Steps() themselves."""
+    from elf_amd import go_game as go
+    co = go.ContextOptions()
+    co.num_games = B
+    opt = go.GameOptions()
+    opt.mode, opt.seed, opt.ply_cap, opt.end_on_two_passes, opt.fuse_selfplay = "selfplay", seed, 722, True, fuse
+    gc = go.GameContext(co, opt)
+    gs = gc.CreateGroupStat()
+    gs.name = "actor"
+    gid = gc.AddCollectors(B, 0, 0, gs)
+    tt = {"float": torch.float32, "unsigned char": torch.uint8}
+    keep = []
+    for which, keys in (("input", ("s", "legal")), ("reply", ("pi", "V"))):
+        for key in keys:
+            info = gc.GetTensorSpec(gid, key, 1)
+            v = torch.ones(*info.sz, dtype=tt[info.type], device="cuda:0")
+            info.p, info.byte_size = v.data_ptr(), v.numel() * v.element_size()
+            gc.AddTensor(gid, which, info)
+            keep.append(v)
+    gc.Start()
+    host = 0.0
+    for i in range(warm + steps):
+        if i == warm:
+            torch.cuda.synchronize()
+            t0, host = time.perf_counter(), 0.0
+        h0 = time.perf_counter()
+        infos = gc.Wait(0)
+        gc.Steps(infos)
+        host += time.perf_counter() - h0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stats = gc.Stats()
+    gc.Stop()
+    return {"moves_per_s": B * steps / dt, "step_ms": dt * 1e3 / steps, "host_us_per_batch": host * 1e6 / steps,
+            "launches_per_step": (1 if B <= 4096 else 2) if fuse else 3, "steps": steps, "games_finished": stats[0],
+            "GBps": B * ALG_BYTES_PER_BOARD / (dt / steps) / 1e9}
+
+
+def cfg3_offline(games=256, batches=150):
+    """BASELINE.json configs[2]: offline SGF replay, batch 256 (tools/time_offline.py in a child process:
+    ours with device tensors, and the UNMODIFIED reference go_game module built under oracle/_ref when
+    it travelled -- one OS thread per game, numpy buffers -- on this host's cores)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "time_offline.py"), "--games", str(games),
+                            "--batches", str(batches)], capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(lines[-1]) if lines else {"error": r.stderr[-300:]}
+    except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+        return {"error": repr(e)}
 
 
 if __name__ == "__main__":

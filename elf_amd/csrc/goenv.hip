@@ -137,51 +137,86 @@ __device__ __forceinline__ void emit_sample_meta(const goenv_sample_out& o, int 
   s.seqtot += 1;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP adds (full-rate VALU; __shfl_up would be
+// six LDS-crossbar permutes): row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast:15 into
+// rows 1 and 3 and row_bcast:31 into rows 2 and 3.  Lanes without a source add 0.
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+
 // Move selection from a policy head: sample p proportional to pi[p] over the LEGAL points, in exact
-// integer arithmetic (weights floor(pi * 2^24)), keyed by the counter RNG; all-zero weights fall
-// back to the cfg-2 random policy.  `row` is indexed in the augmented frame `aug`.  Works on the
-// uniform six-word masks, so every wave of a board computes the same result by itself.
-__device__ __forceinline__ int pick_policy_move(const Masks& m, int lane, const Scalars& s, const float* __restrict__ row,
-                                                int aug, uint64_t seed, uint64_t board_id) {
+// integer arithmetic (weights floor(pi * 2^24), r = floor(u * total / 2^64) with the counter RNG's u,
+// the point whose running sum first exceeds r); all-zero weights fall back to the cfg-2 random
+// policy.  ONE wave does it for its board (lane l weighs points l + 64 j): with several waves per
+// board the others wait at the caller's barrier -- sharing the six words between the waves was
+// measured slower (every wave then pays the uniform part, and the masks live in scalar registers
+// that the kernel is short of: 83 us against 55 us per ply at 8,192 boards).
+// pv[j] = pi of point lane + 64 j in the frame the caller indexed it in (policy_preload).
+__device__ __forceinline__ void policy_preload(int lane, const float* __restrict__ row, int aug, float pv[NWORDS]) {
+  GO_UNROLL
+  for (int j = 0; j < NWORDS; ++j) {
+    const int p = lane + 64 * j;
+    pv[j] = p < NPTS ? row[aug ? d4_dest(aug, p) : p] : 0.f;
+  }
+}
+
+__device__ __forceinline__ int pick_policy_move(const Masks& m, int lane, const Scalars& s, const float pv[NWORDS],
+                                                uint64_t seed, uint64_t board_id) {
   uint32_t pre[NWORDS], sum[NWORDS];
   unsigned long long total = 0;
   GO_UNROLL
-  for (int k = 0; k < NWORDS; ++k) {
-    const int p = lane + 64 * k;
+  for (int j = 0; j < NWORDS; ++j) {
     uint32_t w = 0;
-    if (p < NPTS && ((m.legal[k] >> lane) & 1ull)) {
-      const float f = row[aug ? d4_dest(aug, p) : p];
+    if ((m.legal[j] >> lane) & 1ull) {   // bits beyond point 360 are never set
+      const float f = pv[j];
       if (f > 0.f) {
         const float sc = f * 16777216.0f;
         w = sc >= 16777216.0f ? 16777216u : (uint32_t)sc;
       }
     }
-    uint32_t v = w;
-    GO_UNROLL
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t t = __shfl_up(v, d);
-      if (lane >= d) v += t;
-    }
-    pre[k] = v;
-    sum[k] = __shfl(v, 63);
-    total += sum[k];
+    pre[j] = wave_scan_add(w);
+    sum[j] = (uint32_t)__builtin_amdgcn_readlane((int)pre[j], 63);
+    total += sum[j];
   }
   if (total == 0) return pick_random_move(m, lane, s, seed, board_id);
   const uint64_t u = policy_rand(seed ^ 0xA5A5A5A55A5A5A5Aull, board_id, (uint64_t)s.game, (uint64_t)s.ply);
-  unsigned long long r = u % total;
+  unsigned long long r = __umul64hi(u, total);
   int a = -1;
   GO_UNROLL
-  for (int k = 0; k < NWORDS; ++k) {
+  for (int j = 0; j < NWORDS; ++j) {
     if (a < 0) {
-      if (r < sum[k]) {
-        const unsigned long long hit = __ballot((unsigned long long)pre[k] > r);
-        a = 64 * k + (int)__builtin_ctzll(hit);
+      if (r < sum[j]) {
+        const unsigned long long hit = __ballot((unsigned long long)pre[j] > r);
+        a = 64 * j + (int)__builtin_ctzll(hit);
       } else {
-        r -= sum[k];
+        r -= sum[j];
       }
     }
   }
   return a;
+}
+
+// The sampler as a FUNCTION CALL from the ply kernel, with the masks and the two scalars it needs read
+// again from the record (scalar loads that hit the cache: load_record has just fetched them).  Inlined,
+// it shares the kernel's scalar registers, which the kernel has none to spare of: the allocator then
+// spills them through VGPR lanes all over the plane stores (971 v_readlane against 226 in the ISA, 3,200
+// against 2,530 vector instructions per board-ply, 82 us against 55 us per ply at 8,192 boards).
+__device__ __attribute__((noinline)) int sample_move_of_record(const BoardRec* rec, float p0, float p1, float p2,
+                                                               float p3, float p4, float p5, uint64_t seed,
+                                                               uint64_t board_id) {
+  Masks m;
+  load_masks(rec, m);
+  Scalars s;
+  s.game = rec->sc[SC_GAME];
+  s.ply = rec->sc[SC_PLY];
+  const float pv[NWORDS] = {p0, p1, p2, p3, p4, p5};
+  return pick_policy_move(m, (int)(threadIdx.x & 63), s, pv, seed, board_id);
 }
 
 // One ply for one board held in LDS/registers.  `m` = masks of the position (all words), `o`
@@ -246,6 +281,12 @@ __global__ __launch_bounds__(64 * NW) void k_ply(PlyParams P) {
   return;
 #endif
   BoardRec* rec = P.state + board;
+  // the row's inputs are requested together with the record: one trip to memory, not one per use
+  const int aug = P.aug ? (P.aug[b] & 7) : 0;
+  long long av = 0;
+  if (MODE == 0) av = (long long)P.actions[b];
+  float pv[NWORDS];
+  if (MODE == 2 && g.wave == 0) policy_preload(g.lane, P.pi + (size_t)b * NPTS, P.pi_aug ? (P.pi_aug[b] & 7) : 0, pv);
   Scalars s;
   uint32_t lab[K], lastp[K];
   Masks m;
@@ -277,12 +318,17 @@ __global__ __launch_bounds__(64 * NW) void k_ply(PlyParams P) {
   if (!skip) {
     // the masks of the new position are computed AFTER the planes have been issued: the plane
     // stores then drain to HBM while the workgroup finishes its mask / record tail
-    long long av = 0;
-    if (MODE == 0) av = (long long)P.actions[b];
-    if (MODE == 2) {
-      const int pa = P.pi_aug ? (P.pi_aug[b] & 7) : 0;
-      av = __builtin_amdgcn_readfirstlane(
-          pick_policy_move(m, g.lane, s, P.pi + (size_t)b * NPTS, pa, P.seed, (uint64_t)(P.id_base + board)));
+    if (MODE == 2) {  // wave 0 samples; the other waves of the board take the move from LDS
+      int pa = -1;
+      if (g.wave == 0)
+        pa = sample_move_of_record(rec, pv[0], pv[1], pv[2], pv[3], pv[4], pv[5], P.seed, (uint64_t)(P.id_base + board));
+      if (NW > 1) {
+        if (g.tid == 0) L.xflag[3] = (uint32_t)pa;
+        WSYNC();
+        pa = (int)L.xflag[3];
+      }
+      av = __builtin_amdgcn_readfirstlane(pa);
+      STAMP(2);
     }
     a = ply_body<NW, RANDOM, false>(L, g, lab, lastp, s, m, o, P, board, av);
     status = (a == -4) ? 0 : 1;
@@ -298,7 +344,6 @@ __global__ __launch_bounds__(64 * NW) void k_ply(PlyParams P) {
       fresh = true;
     }
     STAMP(4);
-    const int aug = P.aug ? (P.aug[b] & 7) : 0;
     const int ply_of_sample = s.ply;
     if (P.flags & GOENV_F_COLLECT) emit_sample_meta(P.meta, b, board, g.tid, s, aug);
     (void)ply_of_sample;
@@ -404,7 +449,9 @@ __global__ __launch_bounds__(64) void k_sample_policy(const BoardRec* state, int
   Masks m;
   load_masks(rec, m);
   const int aug = aug_codes ? (aug_codes[b] & 7) : 0;
-  const int a = pick_policy_move(m, lane, s, pi + (size_t)b * NPTS, aug, seed, (uint64_t)(id_base + board));
+  float pv[NWORDS];
+  policy_preload(lane, pi + (size_t)b * NPTS, aug, pv);
+  const int a = pick_policy_move(m, lane, s, pv, seed, (uint64_t)(id_base + board));
   if (lane == 0) actions_out[b] = a;
 }
 
@@ -841,6 +888,9 @@ struct goenv_ctx {
   int zero_first;  // -1 = by batch size, 0 / 1 pinned (GOENV_ZERO_FIRST, tuning only)
   int xcd_map;     // 1 = xcd_row dealing of output rows (default); GOENV_XCD_MAP=0 turns it off (tuning only)
   float lut1;
+  int fuse_max;    // goenv_ply_policy_sel: largest selection whose sampler runs inside the ply kernel
+  int64_t* sampled;      // moves of the two-launch form of goenv_ply_policy_sel; allocated on first use
+  int sampled_cap;
   hipStream_t part_stream[GOENV_MAX_PARTS];  // goenv_ply_repeat_parts; created on first use
   hipEvent_t part_event[GOENV_MAX_PARTS + 1];
   int parts_ready;
@@ -940,6 +990,12 @@ int goenv_create(int device, int n_boards, uint64_t seed, int64_t board_id_base,
   if (const char* e = getenv("GOENV_ZERO_FIRST")) c->zero_first = atoi(e) & 3;
   c->xcd_map = 1;
   if (const char* e = getenv("GOENV_XCD_MAP")) c->xcd_map = atoi(e) ? 1 : 0;
+  // measured (tools/time_api_sweep.py, profiles/r02_api_sweep.txt): up to 4,096 boards one launch wins
+  // (13.1 against 15.7 us at 1,024); beyond, the policy row is one more read in front of every
+  // workgroup's chain while the chip is saturated with plane stores, and the sampler as a small launch
+  // of its own is faster (8,192 boards: 59.7 against 78.2 us)
+  c->fuse_max = 4096;
+  if (const char* e = getenv("GOENV_FUSE_MAX")) c->fuse_max = atoi(e);
   if (const char* e = getenv("GOENV_WAVES_PER_BOARD")) {
     const int v = atoi(e);
     if (v == 1 || v == 2 || v == 3 || v == 6) c->nw = v;
@@ -984,6 +1040,7 @@ int goenv_destroy(goenv_ctx* c) {
   (void)hipFree(c->state);
   (void)hipFree(c->stats);
   (void)hipFree(c->lut);
+  if (c->sampled) (void)hipFree(c->sampled);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   if (c->parts_ready) {
@@ -1064,10 +1121,24 @@ static int ply_sel_impl(goenv_ctx* c, const char* who, const int32_t* idx, int f
                         int32_t* status_out, void* stream) {
   if (check_sel(c, idx, first, count, who)) return -1;
   ON_DEVICE_OF(c);
-  const int mode = pi ? 2 : ((flags & GOENV_F_RANDOM_POLICY) ? 1 : 0);
+  int mode = pi ? 2 : ((flags & GOENV_F_RANDOM_POLICY) ? 1 : 0);
   if (mode == 0 && !actions) return fail("goenv_ply: actions required unless GOENV_F_RANDOM_POLICY is set");
   if ((flags & GOENV_F_COLLECT) && !meta) return fail("goenv_ply: GOENV_F_COLLECT needs a goenv_sample_out");
   if (count == 0) return 0;
+  if (mode == 2 && count > c->fuse_max) {
+    // large selections: the sampler as a launch of its own (one wave per board, all resident at once),
+    // then the ply kernel on the sampled moves -- same moves, same outputs as the fused kernel
+    if (c->sampled_cap < count) {
+      if (c->sampled) HIPCHK(hipFree(c->sampled));
+      c->sampled = nullptr; c->sampled_cap = 0;
+      HIPCHK(hipMalloc((void**)&c->sampled, (size_t)c->n * sizeof(int64_t)));
+      c->sampled_cap = c->n;
+    }
+    hipLaunchKernelGGL(k_sample_policy, dim3(count), dim3(64), 0, S(stream), c->state, c->n, idx, first, count, pi,
+                       pi_aug, c->sampled, c->seed, c->id_base);
+    HIPCHK(hipGetLastError());
+    actions = c->sampled; pi = nullptr; pi_aug = nullptr; mode = 0;
+  }
   PlyParams P = make_params(c, flags, actions, aug_codes, feat_out, legal_out, actions_out, status_out);
   P.n = count; P.idx = idx; P.first = first;
   P.pi = pi; P.pi_aug = pi_aug;
@@ -1089,7 +1160,9 @@ int goenv_ply_policy_sel(goenv_ctx* c, const int32_t* idx, int first, int count,
                          const int32_t* pi_aug_codes, const int32_t* aug_codes, float* feat_out, uint8_t* legal_out,
                          const goenv_sample_out* meta, int32_t* actions_out, int32_t* status_out, void* stream) {
   if (!pi) return fail("goenv_ply_policy_sel: pi is required");
-  if (flags & GOENV_F_RANDOM_POLICY) return fail("goenv_ply_policy_sel: GOENV_F_RANDOM_POLICY does not apply");
+  if (flags & (GOENV_F_RANDOM_POLICY | GOENV_F_AUTO_RESTART))
+    return fail("goenv_ply_policy_sel: GOENV_F_RANDOM_POLICY and GOENV_F_AUTO_RESTART do not apply (the move is "
+                "sampled for the stored position; restart finished games with GOENV_F_RESTART_AFTER_END)");
   return ply_sel_impl(c, "goenv_ply_policy_sel", idx, first, count, flags, nullptr, pi, pi_aug_codes, aug_codes,
                       feat_out, legal_out, meta, actions_out, status_out, stream);
 }
@@ -1152,6 +1225,16 @@ int goenv_ply_repeat_parts(goenv_ctx* c, int n_steps, int n_parts, uint32_t flag
 }
 
 #ifdef GOENV_STAMPS
+// Diagnostic build only: stamps of one fused selfplay step (goenv_ply_policy_sel over all boards).
+extern "C" int goenv_diag_ply_policy(goenv_ctx* c, uint32_t flags, const float* pi, float* feat_out, uint8_t* legal_out,
+                                     unsigned long long* stamps, void* stream) {
+  PlyParams P = make_params(c, flags, nullptr, nullptr, feat_out, legal_out, nullptr, nullptr);
+  P.pi = pi;
+  P.stamps = stamps;
+  GO_LAUNCH_PLY(pick_nw(c, c->n), 2, c->n, S(stream), P);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 // Diagnostic build only: stamps [n][2 waves][16] of the LAST ply of a generator launch (slots 8..12: loop
 // top, rules + masks done, masks gathered, legal written, planes issued; 2, 3 inside the rules).
 extern "C" int goenv_diag_generate(goenv_ctx* c, int n_plies, float* feat_ring, uint8_t* legal_ring,
@@ -1473,6 +1556,17 @@ int goenv_timer_end(goenv_ctx* c, void* stream) {
   ON_DEVICE_OF(c);
   HIPCHK(hipEventRecord(c->ev1, S(stream)));
   return 0;
+}
+// Busy-polls the end event instead of sleeping on it: a blocking synchronise wakes the host tens of
+// microseconds after the GPU is done, which a caller timing a sub-millisecond region would count.
+int goenv_timer_spin(goenv_ctx* c) {
+  if (!c) return fail("goenv_timer_spin: ctx is NULL");
+  ON_DEVICE_OF(c);
+  for (;;) {
+    const hipError_t e = hipEventQuery(c->ev1);
+    if (e == hipSuccess) return 0;
+    if (e != hipErrorNotReady) return fail("goenv_timer_spin: hipEventQuery", e);
+  }
 }
 float goenv_timer_ms(goenv_ctx* c) {
   if (!c) return -1.f;

@@ -81,6 +81,7 @@ _SIGS = {
     "goenv_stats_clear": (C.c_int, [C.c_void_p, C.c_void_p]),
     "goenv_timer_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "goenv_timer_end": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "goenv_timer_spin": (C.c_int, [C.c_void_p]),
     "goenv_timer_ms": (C.c_float, [C.c_void_p]),
     "goenv_aug_action": (C.c_int, [C.c_int, C.c_int]),
     "goenv_aug_action_inv": (C.c_int, [C.c_int, C.c_int]),
@@ -423,6 +424,9 @@ class GoEnv:
 
     def timer_end(self):
         self._chk(self.lib.goenv_timer_end(self._h, self._stream()))
+
+    def timer_spin(self):
+        self._chk(self.lib.goenv_timer_spin(self._h))
 
     def timer_ms(self):
         return float(self.lib.goenv_timer_ms(self._h))

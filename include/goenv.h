@@ -271,9 +271,13 @@ int goenv_ply_sel(goenv_ctx* ctx, const int32_t* idx, int first, int count, uint
  * AIWithCommT::Act does around one reply (elf/ai.h:69-80) and GoGame::Act after it
  * (go/game.cc:80-93): the move is sampled from the policy head `pi` over the legal points
  * (as goenv_sample_policy; pi float32 [count][361], row b in the frame of pi_aug_codes[b],
- * NULL = code 0), applied (flags as goenv_ply_sel: RESET_ILLEGAL, RESTART_AFTER_END, COLLECT ...),
+ * NULL = code 0), applied (flags as goenv_ply_sel: RESET_ILLEGAL, RESTART_AFTER_END, COLLECT ...;
+ * not RANDOM_POLICY or AUTO_RESTART: the move is sampled for the position as stored),
  * and the NEXT sample's planes (frame aug_codes), legal mask and sequencing record are written
- * straight into the batch arrays.  actions_out int32 [count] receives the sampled move. */
+ * straight into the batch arrays.  actions_out int32 [count] receives the sampled move.  One
+ * launch up to 4,096 boards; above, the sampler runs as a small launch of its own in front of
+ * the ply kernel (measured faster there; same moves and outputs; its int64 [n_boards] move buffer
+ * is allocated by the first such call). */
 int goenv_ply_policy_sel(goenv_ctx* ctx, const int32_t* idx, int first, int count, uint32_t flags,
                          const float* pi, const int32_t* pi_aug_codes, const int32_t* aug_codes,
                          float* feat_out, uint8_t* legal_out, const goenv_sample_out* meta,
@@ -405,6 +409,8 @@ int goenv_stats_clear(goenv_ctx* ctx, void* stream);
  * _end bracket a region; goenv_timer_ms synchronises and returns its length. */
 int goenv_timer_begin(goenv_ctx* ctx, void* stream);
 int goenv_timer_end(goenv_ctx* ctx, void* stream);
+/* busy-polls until the end event has passed (a blocking wait wakes up tens of microseconds late) */
+int goenv_timer_spin(goenv_ctx* ctx);
 float goenv_timer_ms(goenv_ctx* ctx);
 
 /* D4 / action helpers (host, pure): go/board_feature.h:38-71.  Actions are

@@ -601,7 +601,9 @@ int goor_sample_policy(const GoBoard* b, uint64_t seed, uint64_t board_id, uint6
     total += w[p];
   }
   if (total == 0) return goor_policy_move(b, seed, board_id, game);
-  uint64_t r = goor_policy_rand(seed ^ 0xA5A5A5A55A5A5A5Aull, board_id, game, (uint64_t)b->ply) % total;
+  /* r = floor(u * total / 2^64): a multiply-high instead of a 64-bit modulo (no divide on the device) */
+  uint64_t u = goor_policy_rand(seed ^ 0xA5A5A5A55A5A5A5Aull, board_id, game, (uint64_t)b->ply);
+  uint64_t r = (uint64_t)(((unsigned __int128)u * total) >> 64);
   uint64_t run = 0;
   for (int p = 0; p < NP; ++p) { run += w[p]; if (run > r) return p; }
   return -1;

@@ -234,13 +234,17 @@ def _selfplay_context(go, N, B, ncoll, seed, fuse, keys, ply_cap=40):
     return gc, gids, ins, outs
 
 
-@pytest.mark.parametrize("N,B,ncoll", [(16, 16, 1), (16, 8, 2), (24, 8, 2), (10, 16, 1)])
-def test_fused_selfplay_step_against_oracle(go, N, B, ncoll):
+@pytest.mark.parametrize("N,B,ncoll,fuse_max", [(16, 16, 1, None), (16, 8, 2, None), (24, 8, 2, None), (10, 16, 1, None),
+                                                 (16, 16, 1, "0")])
+def test_fused_selfplay_step_against_oracle(go, monkeypatch, N, B, ncoll, fuse_max):
     """Selfplay with device tensors and a pi-only reply: Steps() is ONE launch (goenv_ply_policy_sel) that
     samples the move, applies it and writes the games' next samples into the collector's tensors.  Every
     sampled move is predicted by the oracle's sampler from the same pi, every delivered row (planes, mask,
     sequencing record) is checked against an oracle board, and the whole stream equals the unfused path's
-    (Wait extracts, Steps samples + plies: three launches)."""
+    (Wait extracts, Steps samples + plies: three launches).  fuse_max "0" forces the form large selections
+    take: the sampler as a launch of its own in front of the ply kernel."""
+    if fuse_max is not None:
+        monkeypatch.setenv("GOENV_FUSE_MAX", fuse_max)       # read by goenv_create
     seed, cap = 13, 40
     iters = 50 * -(-N // B)                                        # every game passes the ply cap at least once
     keys = ["s", "legal"] + LABELS

@@ -16,15 +16,23 @@ warm = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 lib = goenv.load_library(os.path.join(ROOT, "elf_amd", "libgoenv_diag.so"))
 lib.goenv_diag_ply.restype = C.c_int
 lib.goenv_diag_ply.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+lib.goenv_diag_ply_policy.restype = C.c_int
+lib.goenv_diag_ply_policy.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 5
+POLICY = os.environ.get("STAMPS_POLICY") == "1"     # the fused selfplay step (move sampled from pi) instead
 env = goenv.GoEnv(B, seed=1)
 feat, legal = env.new(torch.float32, 25, 19, 19), env.new(torch.uint8, 361)
 stamps = torch.zeros((B, 32), dtype=torch.int64, device=env.device)   # [board][wave 0 / 1][16]
+pi = torch.ones(B, 361, device=env.device)
 for _ in range(warm):
     env.ply(goenv.F_RANDOM_POLICY | goenv.F_AUTO_RESTART, feat_out=feat, legal_out=legal)
 names = {1: "load_board", 2: "pick_move", 3: "apply+rebuild", 4: "move_masks", 5: "store_state", 6: "legal_out", 7: "features"}
 acc = None
 for rep in range(20):
-    lib.goenv_diag_ply(env._h, goenv.F_AUTO_RESTART, feat.data_ptr(), legal.data_ptr(), stamps.data_ptr(), None)
+    if POLICY:
+        lib.goenv_diag_ply_policy(env._h, goenv.F_RESET_ILLEGAL | goenv.F_RESTART_AFTER_END, pi.data_ptr(), feat.data_ptr(),
+                                  legal.data_ptr(), stamps.data_ptr(), None)
+    else:
+        lib.goenv_diag_ply(env._h, goenv.F_AUTO_RESTART, feat.data_ptr(), legal.data_ptr(), stamps.data_ptr(), None)
     torch.cuda.synchronize()
     s = stamps.cpu()
     idx = [0, 1, 2, 3, 4, 5, 6, 7]
@@ -33,8 +41,12 @@ for rep in range(20):
 acc /= 20
 med = acc.median(0).values
 tot = (s[:, 7] - s[:, 0]).double()
+print("policy-sampled step" if POLICY else "on-device random policy", end=": ")
 print("boards", B, "waves/board", os.environ.get("GOENV_WAVES_PER_BOARD", "auto"), "median cycles of wave 0 per phase:")
 for i, k in enumerate([1, 2, 3, 4, 5, 6, 7]):
     print("  %-14s %9.0f  (%.1f%%)" % (names[k], med[i].item(), 100 * med[i].item() / med.sum().item()))
 print("  total median %.0f  max %.0f" % (tot.median().item(), tot.max().item()))
 print("  grid span (last end - first start): %d" % int(s[:, 7].max() - s[:, 0].min()))
+starts = (s[:, 0] - s[:, 0].min()).double()
+print("  workgroup start times (cycles after the first): median %.0f  p90 %.0f  max %.0f" % (
+    starts.median().item(), starts.quantile(0.9).item(), starts.max().item()))
