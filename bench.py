@@ -1,32 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- 19x19 Go moves/s of the MI355X batched Go environment (BASELINE.json metric).
 
-A "step" is ONE ply of the hot path over the whole batch resident in HBM: on-device cfg-2 policy
-(uniform over legal moves that do not fill an own true eye) -> rules update (TryPlay/Play) ->
-legal mask -> 25 feature planes, all written into device batch buffers.  Finished games are
-scored, counted into the stats vector and restarted in place (as ELF's selfplay restarts games,
-go/game.cc:81-90), so every step applies exactly one move on every board and
-value = n_gpus * boards * steps / time.
+The hot path over the whole batch resident in HBM: on-device cfg-2 policy (uniform over legal moves
+that do not fill an own true eye) -> rules update (TryPlay/Play) -> legal mask -> 25 feature planes,
+all written into device batch buffers.  Finished games are scored, counted into the stats vector and
+restarted in place (as ELF's selfplay restarts games, go/game.cc:81-90), so every ply applies exactly
+one move on every board.
 
-The timed path is the persistent generator (goenv_generate, kernel k_generate): one launch plays
-T plies of every board with the boards kept in LDS/registers and writes ply t's planes, mask and
+A STEP is one pass of the timed kernel over one batch of output: ONE launch of the persistent
+generator (goenv_generate, kernel k_generate), which plays `plies_per_step` plies (default 64, the
+ring depth) of every board with the boards kept in LDS/registers and writes ply t's planes, mask and
 move to slot t of ring buffers -- nothing is skipped against a launch per ply (same bytes, same
-order; tests/test_gpu_entry_points.py holds the two paths bit-identical).  --steps K is cut into
-K/T equal launches (T = the largest divisor of K within the ring depth).  The launch-per-ply path
-(goenv_ply, what a model in the loop uses) is timed beside it under "extra".
+order; tests/test_gpu_entry_points.py holds the two paths bit-identical).  So
+    value = n_gpus * boards * plies_per_step * steps / time      [moves/s]
+and --steps K times exactly K launches.  (Round 1 called a single ply a step; the driver's K = 20 was
+then ONE 0.18-ms launch, a fifth of it launch + sync.)  The launch-per-ply path (goenv_ply) and the
+GameContext API path (what a model in the loop uses) are timed beside it under "extra".
 
 Workload at N=1: BASELINE.json configs[1] -- 1,024 concurrent games, uniform-random legal-move
 playouts to the end, 1 MI355X.  For N>1 every rank runs the same per-GPU batch (weak scaling),
 boards keyed by global id; the only collective is the end-of-run stats all-reduce (RCCL).
 
-Hygiene of the timed region (round 2): the boards are first rolled --preroll plies forward WITHOUT
-outputs (set-up, not warmup) so that they stand in the steady state of continuous selfplay -- games
-of every age, some ending, being scored and restarted inside any window; the warmup runs at least
-one full launch of the timed shape over the WHOLE ring, so no ring slot is first touched inside the
-timed region; the K-step region (barrier + synchronize on both sides) is then timed `reps` times
-back to back and the MEDIAN region is reported (ms_per_step x steps = one region).
+Hygiene of the timed region: the boards are first rolled --preroll plies forward WITHOUT outputs
+(set-up, not warmup) so that they stand in the steady state of continuous selfplay -- games of every
+age, some ending, being scored and restarted inside any window; every warmup step is a full launch
+of the timed shape over the WHOLE ring, so no ring slot is first touched inside the timed region;
+the K-step region (barrier + synchronize on both sides) is timed `reps` times back to back and the
+MEDIAN region is reported (ms_per_step x steps = one region).
 
-    python bench.py --gpus N --steps K --warmup W [--boards B] [--ring R] [--preroll P]
+    python bench.py --gpus N --steps K --warmup W [--boards B] [--ring T] [--preroll P]
 """
 import argparse
 import json
@@ -109,21 +111,19 @@ def measured_traffic(boards, plies_per_launch):
     return None, None
 
 
-def plies_per_launch(steps, ring):
-    """Plies per timed launch: the largest divisor of `steps` within the ring depth, so that equal
-    launches cover EXACTLY `steps`; when `steps` has no divisor above half the ring (a prime, say)
-    the launches are `ring` plies each and the last one is shorter."""
-    t = max(t for t in range(1, min(ring, steps) + 1) if steps % t == 0)
-    return t if 2 * t >= min(ring, steps) else min(ring, steps)
+def plies_per_step(boards, ring, budget_bytes=6e9):
+    """Plies one generator launch plays = ring depth, cut down for big batches so that the ring of
+    planes stays within a few GB (8,192 boards: 20 plies; 65,536: 2)."""
+    return int(max(1, min(ring, budget_bytes // (boards * ALG_BYTES_PER_BOARD_PLY))))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2048)
-    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=32, help="timed generator launches (one step = --ring plies of every board)")
+    ap.add_argument("--warmup", type=int, default=4, help="untimed launches of the same shape before the timed region")
     ap.add_argument("--boards", type=int, default=1024, help="boards per GPU (cfg 2: 1024; cfg 4 shard: 8192)")
-    ap.add_argument("--ring", type=int, default=64, help="ring depth in plies = most plies per generator launch")
+    ap.add_argument("--ring", type=int, default=64, help="ring depth in plies = plies per step (per generator launch)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--preroll", type=int, default=4096,
                     help="plies every board is rolled forward without outputs before the warmup (set-up: steady state)")
@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
-    if args.steps < 1 or args.warmup < 0 or args.ring < 1 or args.boards < 1:
+    if args.steps < 1 or args.warmup < 0 or args.ring < 1 or args.boards < 1 or args.preroll < 0:
         ap.error("--steps, --ring and --boards must be positive, --warmup non-negative")
 
     rank = int(os.environ.get("RANK", "0"))
@@ -162,19 +162,15 @@ def main():
     torch.cuda.set_device(local_rank)
     B = args.boards
     env = goenv.GoEnv(B, device=local_rank, seed=args.seed, board_id_base=rank * B, komi=7.5, max_ply=722)
-    T = plies_per_launch(args.steps, args.ring)
-    R = max(T, min(args.ring, max(args.warmup, 1)))
-    feat = torch.empty(R, B, 25, 19, 19, dtype=torch.float32, device=env.device)   # ring: slot t = ply t of a launch
-    legal = torch.empty(R, B, 361, dtype=torch.uint8, device=env.device)
-    moves = torch.empty(R, B, dtype=torch.int32, device=env.device)
+    T = plies_per_step(B, args.ring)
+    feat = torch.empty(T, B, 25, 19, 19, dtype=torch.float32, device=env.device)   # ring: slot t = ply t of a launch
+    legal = torch.empty(T, B, 361, dtype=torch.uint8, device=env.device)
+    moves = torch.empty(T, B, dtype=torch.int32, device=env.device)
 
-    def steps(k, per):
-        # k plies of every board as launches of `per` plies of the persistent generator (the last
-        # one shorter if `per` does not divide k -- warmup only); launches queue back to back
-        while k > 0:
-            t = min(per, k)
-            env.generate(t, feat[:t], legal[:t], moves[:t])
-            k -= t
+    def steps(k):
+        # k steps = k launches of the persistent generator, T plies of every board each, queued back to back
+        for _ in range(k):
+            env.generate(T, feat, legal, moves)
 
     def sync():
         torch.cuda.synchronize()
@@ -182,23 +178,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # set-up: into the steady state of continuous selfplay (no outputs: a few ms), statistics restarted
-    done = 0
-    while done < args.preroll:
-        t = min(1024, args.preroll - done)
-        env.generate(t, None, None, None)
-        done += t
+    # set-up: into the steady state of continuous selfplay, statistics restarted.  No outputs, and through the
+    # launch-per-ply kernel (same positions): a profile of this command then shows k_generate with full
+    # launches of the timed shape only
+    env.ply_repeat(args.preroll, goenv.F_RANDOM_POLICY | goenv.F_AUTO_RESTART)
     env.stats_clear()
-    # warmup: W plies, and at least one full launch of the timed shape over the whole ring
-    warm_plies = max(args.warmup, R)
-    steps(warm_plies, R)
-    launches = -(-args.steps // T)
+    # warmup: W full launches of the timed shape (each covers the whole ring); never fewer than one
+    warm_steps = max(args.warmup, 1)
+    steps(warm_steps)
+    launches = args.steps
 
     def region():
         sync()
         env.timer_begin()
         t0 = time.perf_counter()
-        steps(args.steps, T)
+        steps(args.steps)
         env.timer_end()
         env.timer_spin()                              # poll, do not sleep, until the last launch is done
         torch.cuda.synchronize()
@@ -224,10 +218,10 @@ def main():
     env.finish()
     stats = reduce_stats(env.stats_tensor()).cpu().tolist()
 
-    value = world * B * args.steps / elapsed
-    alg_launch = B * (args.steps / launches * ALG_BYTES_PER_BOARD_PLY + 2 * REC_BYTES)   # average launch
+    value = world * B * T * args.steps / elapsed
+    alg_launch = B * (T * ALG_BYTES_PER_BOARD_PLY + 2 * REC_BYTES)
     achieved = alg_launch / (kernel_ms * 1e-3) / 1e9
-    traffic, traffic_src = measured_traffic(B, args.steps / launches)
+    traffic, traffic_src = measured_traffic(B, T)
     out = {
         "metric": "19x19 Go moves/sec (node, 1/2/4/8 GPU) + feature-extract HBM GB/s",
         "value": value, "unit": "moves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -236,12 +230,13 @@ def main():
         "config": {"workload": "cfg2: %d concurrent 19x19 games per GPU, on-device uniform-random legal-move "
                                "playouts to the end (scored, counted, restarted in place); every ply of every "
                                "board = rules update + legal mask + 25 planes + the move, written to slot t of "
-                               "device ring buffers by the persistent generator (goenv_generate, %d plies per "
-                               "launch)" % (B, T),
+                               "device ring buffers by the persistent generator (goenv_generate); one step = one "
+                               "launch = %d plies of every board" % (B, T),
                    "boards_per_gpu": B, "global_boards": world * B, "ply_cap": 722,
-                   "plies_per_launch": args.steps / launches, "launches": launches, "parallelism": "shard%d" % world,
+                   "plies_per_step": T, "moves_per_step_per_gpu": B * T, "launches": launches,
+                   "parallelism": "shard%d" % world,
                    "collective_backend": backend if world > 1 else None,
-                   "preroll_plies": args.preroll, "warmup_plies_run": warm_plies, "reps": len(regions),
+                   "preroll_plies": args.preroll, "warmup_steps_run": warm_steps, "reps": len(regions),
                    "region_ms": [round(r[0] * 1e3, 4) for r in regions], "reported": "median region"},
         "roofline": {"bound": "hbm", "kernel": "k_generate", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

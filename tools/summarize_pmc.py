@@ -4,7 +4,12 @@
 
 HBM bytes are corrected as MI355X_MICROARCH.md (HBM / rocprofv3 section) prescribes: FETCH_SIZE and
 WRITE_SIZE are reported in KB; FETCH_SIZE is doubled on gfx950.
-Usage: tools/summarize_pmc.py gpurun_out/<tag> <round>          e.g. ... gpurun_out/r01c r01"""
+Usage: tools/summarize_pmc.py [--last=N] gpurun_out/<tag> <round> [kernel boards plies per_ply_bytes per_launch_bytes]
+       (--last=N: only the last N launches of the kernel, i.e. the timed ones -- bench.py's set-up rolls
+        the boards forward with the same kernel and no outputs)
+       e.g. ... gpurun_out/r02a r02                                   (the bench line: k_generate<2>, 1,024 x 64)
+            ... gpurun_out/r02g8 r02_generate_8192 "k_generate<3>" 8192 20
+            ... gpurun_out/r02p8 r02_ply_8192 "k_ply<3, 1>" 8192 1 36461 3264   (launch per ply)"""
 import csv
 import json
 import os
@@ -20,20 +25,37 @@ ALGO_PER_BOARD_PLY = 36100 + 361 + 4         # planes + mask + move, per board p
 ALGO_PER_BOARD_LAUNCH = 1632 + 1632          # record read + record write, once per launch
 
 
+LAST = 0                                     # > 0: only the last LAST launches of KERNEL (the timed ones)
+
+
 def per_launch(path):
     """counter name -> average over the launches of KERNEL (summed over XCDs/dimensions)."""
-    tot, calls = defaultdict(float), defaultdict(set)
+    rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
-            if KERNEL not in r["Kernel_Name"]:
-                continue
-            tot[r["Counter_Name"]] += float(r["Counter_Value"])
-            calls[r["Counter_Name"]].add(r["Dispatch_Id"])
+            if KERNEL in r["Kernel_Name"]:
+                rows.append((int(r["Dispatch_Id"]), r["Counter_Name"], float(r["Counter_Value"])))
+    ids = sorted({r[0] for r in rows})
+    keep = set(ids[-LAST:] if LAST else ids)
+    tot, calls = defaultdict(float), defaultdict(set)
+    for d, name, v in rows:
+        if d in keep:
+            tot[name] += v
+            calls[name].add(d)
     return {k: tot[k] / len(calls[k]) for k in tot}, max((len(v) for v in calls.values()), default=0)
 
 
 def main():
+    global KERNEL, BOARDS, PLIES, ALGO_PER_BOARD_PLY, ALGO_PER_BOARD_LAUNCH, LAST
+    for a in list(sys.argv):
+        if a.startswith("--last="):
+            LAST = int(a.split("=")[1])
+            sys.argv.remove(a)
     src, rnd = sys.argv[1], sys.argv[2]
+    if len(sys.argv) > 5:
+        KERNEL, BOARDS, PLIES = sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+    if len(sys.argv) > 7:
+        ALGO_PER_BOARD_PLY, ALGO_PER_BOARD_LAUNCH = int(sys.argv[6]), int(sys.argv[7])
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prof = os.path.join(here, "profiles")
     shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(prof, rnd + "_kernel_stats.csv"))
@@ -44,7 +66,10 @@ def main():
     with open(os.path.join(src, "trace", "t_kernel_trace.csv")) as f:
         for r in csv.DictReader(f):
             if KERNEL in r["Kernel_Name"]:
-                dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                dur.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    dur = [d for _, d in sorted(dur)]
+    if LAST:
+        dur = dur[-LAST:]
     avg_us = sum(dur) / len(dur) / 1e3
     fetch, n = per_launch(os.path.join(src, "fetch", "f_counter_collection.csv"))
     write, _ = per_launch(os.path.join(src, "write", "w_counter_collection.csv"))
@@ -65,7 +90,7 @@ def main():
     md.append("| counter | avg per launch | bytes |\n|---|---|---|")
     md.append("| WRITE_SIZE | %.1f KB | %.2f MB (dwordx4 streaming stores: exact per the guide) |" % (write["WRITE_SIZE"], wb / 1e6))
     md.append("| FETCH_SIZE | %.1f KB raw | x2 gfx950 correction = %.2f MB (record loads, history table; narrow widths are uncalibrated: upper bound) |\n" % (fetch["FETCH_SIZE"], fb / 1e6))
-    md.append("Algorithmic bytes per launch = %d boards x (%d plies x (36,100 planes + 361 mask + 4 move) + 1,632 record read + 1,632 record write)" % (BOARDS, PLIES))
+    md.append("Algorithmic bytes per launch = %d boards x (%d plies x %d (planes 36,100 + mask 361 [+ move 4]) + %d (record read + record write))" % (BOARDS, PLIES, ALGO_PER_BOARD_PLY, ALGO_PER_BOARD_LAUNCH))
     md.append("= %.2f MB.  Measured traffic = %.2f MB -> %.3fx algorithmic: no wasted re-reads, the kernel is a" % (algo / 1e6, (wb + fb) / 1e6, out["ratio"]))
     md.append("write stream.  Average kernel duration in the same trace: %.2f us = %.2f us per ply.\n" % (avg_us, avg_us / PLIES))
     md.append("Wave-state counters (SQ, summed over the %d waves of a launch):\n" % waves)
