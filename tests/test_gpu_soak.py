@@ -99,3 +99,73 @@ def test_generator_rings_every_float(boards, plies, launches):
     for b in range(0, boards, 37):
         assert_canon_equal({k: v[b] for k, v in st.items()}, oracles[b].canonical(), "board %d" % b)
     env.close()
+
+
+@pytest.mark.parametrize("boards,cap,plies,launches", [(256, 50, 64, 3), (96, 722, 64, 10)])
+def test_generator_across_game_ends_against_oracle(boards, cap, plies, launches):
+    """Games END inside a generator launch: the kernel scores them (Tromp-Taylor, go/board.cc:1584-1692),
+    counts them into the stats vector and restarts them in place, all between two plies of one launch.
+    A low ply cap ends every game several times per launch; the long run ends most games by two passes.
+    Every ring slot (move, mask, all planes) and the final stats vector against oracle boards that are
+    restarted where the device restarted, with wins from tt_score - komi."""
+    from elf_amd import goenv
+    goenv.load_library()
+    seed, komi = 29, 7.5
+    env = goenv.GoEnv(boards, seed=seed, komi=komi, max_ply=cap)
+    dev = env.device
+    feat = torch.empty(plies, boards, 25, 19, 19, device=dev)
+    legal = torch.empty(plies, boards, 361, dtype=torch.uint8, device=dev)
+    moves = torch.empty(plies, boards, dtype=torch.int32, device=dev)
+    oracles = [OracleBoard() for _ in range(boards)]
+    game = [0] * boards
+    want = [0] * 16
+
+    def ended(o):
+        return o.is_game_end() or o.canonical()["scalars"][0] > cap
+
+    def account(o):
+        sc = o.canonical()["scalars"]
+        n, score = int(sc[0]) - 1, o.tt_score()
+        want[goenv.ST_GAMES] += 1
+        margin = score - komi
+        want[goenv.ST_BLACK_WINS if margin > 0 else (goenv.ST_WHITE_WINS if margin < 0 else goenv.ST_DRAWS)] += 1
+        want[goenv.ST_PLIES] += n
+        want[goenv.ST_BCAP] += int(sc[2])
+        want[goenv.ST_WCAP] += int(sc[3])
+        want[goenv.ST_SUM_LEN2] += n * n
+        want[goenv.ST_PLY_CAP_HITS] += 0 if o.is_game_end() else 1
+        want[goenv.ST_MAX_LEN] = max(want[goenv.ST_MAX_LEN], n)
+        want[goenv.ST_SUM_SCORE] += int(score)
+
+    bad = natural = 0
+    for _ in range(launches):
+        feat.fill_(-3.0)
+        legal.fill_(9)
+        env.generate(plies, feat, legal, moves)
+        mv = moves.cpu().numpy()
+        for t in range(plies):
+            f = feat[t].cpu().numpy().reshape(boards, -1)
+            lg = legal[t].cpu().numpy()
+            for b in range(boards):
+                o = oracles[b]
+                if ended(o):                              # the device restarts it before this ply
+                    natural += o.is_game_end()
+                    account(o)
+                    o = oracles[b] = OracleBoard()
+                    game[b] += 1
+                assert int(mv[t, b]) == o.policy_move(seed, b, game[b]), (t, b)
+                assert o.forward(int(mv[t, b]))[0]
+                if not np.array_equal(f[b], o.extract(0)) or not np.array_equal(lg[b], o.legal()):
+                    bad += 1
+    assert bad == 0, "%d board-plies differ from the oracle" % bad
+    assert want[goenv.ST_GAMES] >= boards // 2
+    if cap >= 700:
+        assert natural > boards // 4, "too few games ended by two passes (%d)" % natural
+    mid = env.stats()                                     # counted inside the launches: games already restarted
+    assert mid == want, (mid, want)
+    env.finish()                                          # + finished boards still waiting for their restart
+    for o in oracles:
+        if ended(o):
+            account(o)
+    assert env.stats() == want
+    env.close()
