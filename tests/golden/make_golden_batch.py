@@ -126,6 +126,14 @@ RUNS = [
          ratio=0.1, cutoff=-1, k=3, samples=200, lst="one.lst"),
 ]
 
+# BASELINE.json configs[2] at its stated size: 256 games in ONE batch of 256 (one collector,
+# num_games == batchsize), go/game.py's default of 5 records per game thread, random D4.  Kept in a
+# file of its own (batch256_streams.json): `make_golden_batch.py --batch256` writes only that.
+RUNS_256 = [
+    dict(name="cfg3_batch256", seed=7, num_games=256, games_per_thread=5, data_aug=-1, start_ratio=0.5, ratio=0.0,
+         cutoff=-1, k=3, samples=12, lst="train.lst"),
+]
+
 QUIRK_TEXTS = [
     "(;GM[1]SZ[19]RE[b+R]HA[4];B[pd];W[];B[tt];W[dd])", "(;GM[1];B[aa]\nW[bb];W[cc])",
     "(;GM[1];B[aa]C[x \\] ;B[bb] y];W[cc])", "(;GM[1];B[aa](;W[bb])(;W[cc]))", "(;GM[1];B[aa];(;W[bb]);W[cc])",
@@ -197,12 +205,33 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--run":     # child: one configuration, then leave hard
         sys.path.insert(0, os.path.dirname(so[0]))
         import go_game as go
-        st = run_reference(go, RUNS[int(sys.argv[2])])
+        st = run_reference(go, (RUNS + RUNS_256)[int(sys.argv[2])])
         dump_json(sys.argv[3], st)
         sys.stdout.flush()
         os._exit(0)
     import subprocess
     import tempfile
+    if "--batch256" in sys.argv:                          # the corpus stays as committed
+        with open(os.path.join(CORPUS, "train.lst")) as f:
+            names = f.read().split()
+        out = dict(corpus=names, fields=KEYS[2:] + ["offline_a", "s_fnv"], runs=[])
+        for i, cfg in enumerate(RUNS_256):
+            with tempfile.TemporaryDirectory() as td:
+                tmp = os.path.join(td, "run.json")
+                for attempt in range(4):
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--run", str(len(RUNS) + i), tmp],
+                                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+                    if r.returncode == 0 and os.path.exists(tmp):
+                        break
+                else:
+                    raise SystemExit("reference run %s failed" % cfg["name"])
+                with open(tmp) as f:
+                    st = json.load(f)
+            out["runs"].append(dict(cfg=cfg, streams=st))
+            print(cfg["name"], len(st), "games x", cfg["samples"], "samples", flush=True)
+        dump_json(os.path.join(GOLDEN, "batch256_streams.json"), out)
+        print("written", os.path.join(GOLDEN, "batch256_streams.json"))
+        return
     names = make_corpus()
     # what the reference's Sgf::Load makes of every corpus file (oracle/_ref/libgoref.so)
     from oracle.pyoracle import RefBoard

@@ -53,7 +53,18 @@ def host(v):
 
 @pytest.mark.parametrize("device", [False, True])
 def test_offline_streams_equal_the_reference_module(go, device):
-    gold = load_golden("batch_streams.json")
+    check_offline_streams(go, device, "batch_streams.json")
+
+
+@pytest.mark.parametrize("device", [False, True])
+def test_cfg3_batch_256_equals_the_reference_module(go, device):
+    """BASELINE.json configs[2] at its stated size: 256 games, ONE batch of 256 per Wait, random D4, k = 3
+    (tests/golden/batch256_streams.json, made by the compiled reference module with the same options)."""
+    check_offline_streams(go, device, "batch256_streams.json", full_batches=True)
+
+
+def check_offline_streams(go, device, golden, full_batches=False):
+    gold = load_golden(golden)
     for run in gold["runs"]:
         cfg = run["cfg"]
         co = go.ContextOptions()
@@ -75,6 +86,8 @@ def test_offline_streams_equal_the_reference_module(go, device):
             infos = gc.Wait(0)
             assert infos.gid == gid and len(infos.s) == B
             h = {k: host(v) for k, v in bufs.items()}
+            if full_batches:                                   # every game exactly once per batch
+                assert sorted(int(g) for g in h["id"][0]) == list(range(B))
             for r in range(len(infos.s)):
                 g = int(h["id"][0, r])
                 assert g == infos.s[r]
