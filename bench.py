@@ -321,6 +321,8 @@ def extra_measurements(goenv, seed):
             res["game_context_selfplay_%d" % B]["moves_per_s"] / res["launch_per_ply_%d" % B]["moves_per_s"])
         res["game_context_selfplay_%d" % B]["unfused_round1_path"] = game_context_selfplay(B, seed, False, steps=300)
     res["cfg3_offline_256"] = cfg3_offline()
+    res["cfg5_selfplay_fp32"] = cfg5_selfplay(["--num_games", "1024", "--batchsize", "1024", "--iters", "15"])
+    res["cfg5_selfplay_bf16"] = cfg5_selfplay(["--num_games", "2048", "--batchsize", "2048", "--iters", "15", "--bf16"])
     env = goenv.GoEnv(1024, seed=seed, max_ply=722)
     nm = env.new(torch.int32)
     env.playout(None, nm)
@@ -377,6 +379,20 @@ def game_context_selfplay(B, seed, fuse, steps=1500, warm=100):
     return {"moves_per_s": B * steps / dt, "step_ms": dt * 1e3 / steps, "host_us_per_batch": host * 1e6 / steps,
             "launches_per_step": (1 if B <= 4096 else 2) if fuse else 3, "steps": steps, "games_finished": stats[0],
             "GBps": B * ALG_BYTES_PER_BOARD / (dt / steps) / 1e9}
+
+
+def cfg5_selfplay(flags):
+    """BASELINE.json configs[4] on one GPU: the df_selfplay loop with a df_model2-shaped 20-block x 128-channel
+    PyTorch-ROCm net, random weights, moves sampled on the device from pi (tools/df_selfplay_gpu.py in a child
+    process; the 8-GPU form is the same tool under torch.distributed.run)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "df_selfplay_gpu.py"), "--json"] + flags,
+                           capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(lines[-1]) if lines else {"error": r.stderr[-300:]}
+    except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+        return {"error": repr(e)}
 
 
 def cfg3_offline(games=256, batches=150):

@@ -49,8 +49,8 @@ class DevBuf {
 // The boards of one GameContext on one GPU.
 class DeviceEnv {
  public:
-  DeviceEnv(int device, int n_boards, uint64_t seed, float komi, int max_ply) : n_(n_boards) {
-    chk(goenv_create(device, n_boards, seed, 0, komi, max_ply, &ctx_), "goenv_create");
+  DeviceEnv(int device, int n_boards, uint64_t seed, int64_t id_base, float komi, int max_ply) : n_(n_boards) {
+    chk(goenv_create(device, n_boards, seed, id_base, komi, max_ply, &ctx_), "goenv_create");
   }
   DeviceEnv(const DeviceEnv&) = delete;
   DeviceEnv& operator=(const DeviceEnv&) = delete;

@@ -84,6 +84,8 @@ struct GameOptions {
                                    // restarts only on an illegal move, go/game.cc:81-90)
   bool signal_restart = false;     // selfplay: restart -> game_counter++, seq=0, last_terminal=1
                                    // (the reference's Go loop never calls AIComm::Restart there)
+  int64_t board_id_base = 0;       // global id of game 0 (rank * num_games in a sharded job): the on-device
+                                   // RNG is keyed by the global id, so ranks play different games
   bool fuse_selfplay = true;       // selfplay with device tensors: Steps() = ONE launch that also writes the
                                    // games' next samples (false: Wait() extracts them, as in round 1)
 };
@@ -316,7 +318,8 @@ class GameContext {
     const int pool = mcts_ ? co_.mcts_options.num_threads * co_.mcts_options.num_rollout_per_thread : 0;
     const long long n_boards = (long long)co_.num_games * (mcts_ ? 1 + pool : npt);
     if (n_boards > (1ll << 30)) throw std::range_error("Start(): num_games x node pool exceeds 2^30 boards");
-    env_.reset(new DeviceEnv(opt_.gpu, (int)n_boards, opt_.seed ? opt_.seed : 1, opt_.komi, opt_.ply_cap));
+    env_.reset(new DeviceEnv(opt_.gpu, (int)n_boards, opt_.seed ? opt_.seed : 1, opt_.board_id_base, opt_.komi,
+                             opt_.ply_cap));
     env_->set_stream(stream_);
     games_.clear();
     games_.resize(co_.num_games);
@@ -1056,6 +1059,7 @@ PYBIND11_MODULE(go_game, m) {
       .def_readwrite("ply_cap", &GameOptions::ply_cap)
       .def_readwrite("end_on_two_passes", &GameOptions::end_on_two_passes)
       .def_readwrite("signal_restart", &GameOptions::signal_restart)
+      .def_readwrite("board_id_base", &GameOptions::board_id_base)
       .def_readwrite("fuse_selfplay", &GameOptions::fuse_selfplay);
 
   py::class_<EntryInfo>(m, "EntryInfo")

@@ -4,8 +4,10 @@
 // batch of B boards is B workgroups.  NW is chosen per launch from the batch size (small batches
 // are latency-bound and take more waves per board; large ones are HBM-bound and take one) or
 // pinned with goenv_set_waves_per_board.  All kernels are stream-ordered on the caller's stream.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <rccl/rccl.h>   // types and enums only: librccl.so is opened at the first collective call
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -925,6 +927,10 @@ static int pick_nw(const goenv_ctx* c, int count) {
   return 3;
 }
 
+// the stats vector is followed by one scratch word (the MAX slot travels through it in
+// goenv_stats_allreduce)
+constexpr int STATS_ALLOC = GOENV_NUM_STATS + 2;
+
 static thread_local std::string g_err;
 
 static int fail(const char* what, hipError_t e = hipSuccess) {
@@ -1009,11 +1015,11 @@ int goenv_create(int device, int n_boards, uint64_t seed, int64_t board_id_base,
   hipError_t e;
   const char* what = "goenv_create: hipMalloc";
   if ((e = hipMalloc((void**)&c->state, (size_t)n_boards * sizeof(BoardRec))) == hipSuccess &&
-      (e = hipMalloc((void**)&c->stats, GOENV_NUM_STATS * sizeof(unsigned long long))) == hipSuccess &&
+      (e = hipMalloc((void**)&c->stats, STATS_ALLOC * sizeof(unsigned long long))) == hipSuccess &&
       (e = hipMalloc((void**)&c->lut, HIST_LUT_N * sizeof(float))) == hipSuccess) {
     what = "goenv_create: initialising the boards";
     if ((e = hipMemcpy(c->lut, lut.data(), HIST_LUT_N * sizeof(float), hipMemcpyHostToDevice)) == hipSuccess &&
-        (e = hipMemset(c->stats, 0, GOENV_NUM_STATS * sizeof(unsigned long long))) == hipSuccess &&
+        (e = hipMemset(c->stats, 0, STATS_ALLOC * sizeof(unsigned long long))) == hipSuccess &&
         (e = hipMemset(c->state, 0, (size_t)n_boards * sizeof(BoardRec))) == hipSuccess &&
         (e = hipEventCreate(&c->ev0)) == hipSuccess && (e = hipEventCreate(&c->ev1)) == hipSuccess) {
       GO_LAUNCH(pick_nw(c, n_boards), k_reset, n_boards, 0, c->state, n_boards, nullptr, n_boards, nullptr);
@@ -1535,6 +1541,53 @@ int goenv_stats_host(goenv_ctx* c, int64_t* out16_host, void* stream) {
   ON_DEVICE_OF(c);
   HIPCHK(hipMemcpyAsync(out16_host, c->stats, GOENV_NUM_STATS * sizeof(int64_t), hipMemcpyDeviceToHost, S(stream)));
   HIPCHK(hipStreamSynchronize(S(stream)));
+  return 0;
+}
+
+// RCCL, opened on first use: the library stays loadable (and every other entry point usable) on a
+// host without RCCL, and a single-GPU process never maps it.
+struct RcclApi {
+  ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*error_string)(ncclResult_t) = nullptr;
+  bool tried = false;
+};
+static RcclApi g_rccl;
+static std::mutex g_rccl_mu;
+
+static int rccl_load() {
+  std::lock_guard<std::mutex> lock(g_rccl_mu);
+  if (!g_rccl.tried) {
+    g_rccl.tried = true;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (h) {
+      g_rccl.all_reduce = reinterpret_cast<decltype(g_rccl.all_reduce)>(dlsym(h, "ncclAllReduce"));
+      g_rccl.error_string = reinterpret_cast<decltype(g_rccl.error_string)>(dlsym(h, "ncclGetErrorString"));
+    }
+  }
+  if (!g_rccl.all_reduce) return fail("goenv_stats_allreduce: librccl.so (ncclAllReduce) cannot be loaded");
+  return 0;
+}
+
+// End-of-episode collective: the stats vector summed over the ranks of `rccl_comm`, slot
+// GOENV_ST_MAX_LEN reduced with MAX, in place, ordered on `stream`.  Two tiny all-reduces: latency only.
+int goenv_stats_allreduce(goenv_ctx* c, void* rccl_comm, void* stream) {
+  if (!c) return fail("goenv_stats_allreduce: ctx is NULL");
+  if (!rccl_comm) return fail("goenv_stats_allreduce: communicator is NULL");
+  if (rccl_load()) return -1;
+  ON_DEVICE_OF(c);
+  unsigned long long* st = c->stats;
+  unsigned long long* mx = c->stats + GOENV_NUM_STATS;
+  HIPCHK(hipMemcpyAsync(mx, st + GOENV_ST_MAX_LEN, sizeof(*mx), hipMemcpyDeviceToDevice, S(stream)));
+  ncclResult_t r = g_rccl.all_reduce(st, st, GOENV_NUM_STATS, ncclInt64, ncclSum, (ncclComm_t)rccl_comm, S(stream));
+  if (r == ncclSuccess) r = g_rccl.all_reduce(mx, mx, 1, ncclInt64, ncclMax, (ncclComm_t)rccl_comm, S(stream));
+  if (r != ncclSuccess) {
+    fail("goenv_stats_allreduce: ncclAllReduce");
+    g_err += ": ";
+    g_err += g_rccl.error_string ? g_rccl.error_string(r) : "RCCL error";
+    return -1;
+  }
+  HIPCHK(hipMemcpyAsync(st + GOENV_ST_MAX_LEN, mx, sizeof(*mx), hipMemcpyDeviceToDevice, S(stream)));
   return 0;
 }
 

@@ -2,7 +2,8 @@
 
 Counterpart of the reference's ``go/game.py`` ``Loader`` (go/game.py:17-102) without the
 rlpytorch ``ArgsProvider`` machinery (plain ``argparse``): same flag names and defaults, same
-batch descriptors per mode (go/game.py:64-93), same ``params`` (go/game_context.h:56-65).
+batch descriptors per mode (go/game.py:64-93), `--use_mcts` and the `--mcts_*` flags of
+elf/context_utils.py:16-69, same ``params`` (go/game_context.h:56-65).
 Extra labels (``--additional_labels id,seq,...``, elf/more_labels.py) are appended to every
 descriptor's input keys.
 """
@@ -22,6 +23,14 @@ def add_arguments(parser=None):
     p.add_argument("--verbose_comm", action="store_true")
     p.add_argument("--verbose_collector", action="store_true")
     p.add_argument("--wait_per_group", action="store_true")
+    p.add_argument("--mcts_threads", type=int, default=0)
+    p.add_argument("--mcts_rollout_per_thread", type=int, default=1)
+    p.add_argument("--mcts_verbose", action="store_true")
+    p.add_argument("--mcts_save_tree_filename", default="")
+    p.add_argument("--mcts_verbose_time", action="store_true")
+    p.add_argument("--mcts_use_prior", action="store_true")
+    p.add_argument("--mcts_pseudo_games", type=int, default=0)
+    p.add_argument("--mcts_pick_method", default="most_visited")
     # go/game.py:24-36
     p.add_argument("--actor_only", action="store_true")
     p.add_argument("--list_file", default="./train.lst")
@@ -32,6 +41,7 @@ def add_arguments(parser=None):
     p.add_argument("--num_games_per_thread", type=int, default=5)
     p.add_argument("--move_cutoff", type=int, default=-1)
     p.add_argument("--mode", default="online", help="online | selfplay | offline")
+    p.add_argument("--use_mcts", action="store_true")
     p.add_argument("--gpu", type=int, default=None)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--num_future_actions", type=int, default=3)
@@ -41,6 +51,8 @@ def add_arguments(parser=None):
     p.add_argument("--end_on_two_passes", action="store_true")
     p.add_argument("--signal_restart", action="store_true")
     p.add_argument("--legal_mask", action="store_true", help="add the `legal` key to the actor inputs")
+    p.add_argument("--board_id_base", type=int, default=0,
+                   help="global id of game 0 (rank * num_games in a sharded job): keys the on-device RNG")
     return p
 
 
@@ -73,10 +85,21 @@ def initialize(args):
     co.verbose_comm = args.verbose_comm
     co.verbose_collector = args.verbose_collector
     co.wait_per_group = args.wait_per_group
+    co.max_num_threads = args.mcts_threads            # elf/context_utils.py:46-69
+    mcts = co.mcts_options
+    mcts.num_threads = args.mcts_threads
+    mcts.num_rollout_per_thread = args.mcts_rollout_per_thread
+    mcts.verbose = args.mcts_verbose
+    mcts.verbose_time = args.mcts_verbose_time
+    mcts.save_tree_filename = args.mcts_save_tree_filename
+    mcts.use_prior = args.mcts_use_prior
+    mcts.pseudo_games = args.mcts_pseudo_games
+    mcts.pick_method = args.mcts_pick_method
     opt = go.GameOptions()
     opt.seed = args.seed
     opt.list_filename = args.list_file
     opt.mode = args.mode
+    opt.use_mcts = args.use_mcts                      # go/game.py:34,51
     opt.verbose = args.verbose
     opt.data_aug = args.data_aug
     opt.ratio_pre_moves = args.ratio_pre_moves
@@ -88,6 +111,7 @@ def initialize(args):
     opt.ply_cap = args.ply_cap
     opt.end_on_two_passes = args.end_on_two_passes
     opt.signal_restart = args.signal_restart
+    opt.board_id_base = args.board_id_base
     GC = go.GameContext(co, opt)
     params = GC.GetParams()
     params.update(dict(num_group=1 if args.actor_only else 2, T=args.T))

@@ -79,6 +79,7 @@ _SIGS = {
     "goenv_stats_ptr": (C.c_void_p, [C.c_void_p]),
     "goenv_stats_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
     "goenv_stats_clear": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "goenv_stats_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "goenv_timer_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "goenv_timer_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "goenv_timer_spin": (C.c_int, [C.c_void_p]),
@@ -415,6 +416,10 @@ class GoEnv:
         buf = (C.c_int64 * NUM_STATS)()
         self._chk(self.lib.goenv_stats_host(self._h, buf, self._stream()))
         return list(buf)
+
+    def stats_allreduce(self, rccl_comm):
+        """goenv_stats_allreduce with a raw ncclComm_t (an int / c_void_p)."""
+        self._chk(self.lib.goenv_stats_allreduce(self._h, C.c_void_p(rccl_comm), self._stream()))
 
     def stats_clear(self):
         self._chk(self.lib.goenv_stats_clear(self._h, self._stream()))

@@ -403,6 +403,13 @@ int goenv_finish(goenv_ctx* ctx, void* stream);
 int64_t* goenv_stats_ptr(goenv_ctx* ctx);
 int goenv_stats_host(goenv_ctx* ctx, int64_t* out16_host, void* stream);
 int goenv_stats_clear(goenv_ctx* ctx, void* stream);
+/* goenv_stats_allreduce: the one collective of a sharded job for hosts that hold an RCCL
+ * communicator themselves (a C++ host keeping ELF's own GameContext; Python callers use
+ * torch.distributed on goenv_stats_ptr, elf_amd/sharding.py).  rccl_comm = ncclComm_t of a
+ * communicator with one rank per GPU; the context's stats vector becomes the SUM over the ranks
+ * (slot GOENV_ST_MAX_LEN: the MAX), in place, ordered on `stream`.  librccl.so is opened by the first
+ * call.  No counterpart in the reference (it is single-process). */
+int goenv_stats_allreduce(goenv_ctx* ctx, void* rccl_comm, void* stream);
 
 /* Timing helper for bench.py: HIP events on the stream the kernels run on
  * (torch.cuda.Event only sees torch's current stream).  goenv_timer_begin /
