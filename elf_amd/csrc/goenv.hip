@@ -356,10 +356,10 @@ __global__ __launch_bounds__(64 * NW) void k_ply(PlyParams P) {
 #endif
       float* out = P.feat + (size_t)b * GOENV_FEAT_FLOATS;
       switch (P.zero_first & 3) {
-        case 0: write_features<NW, true, false>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
-        case 1: write_features<NW, false, false>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
-        case 2: write_features<NW, true, true>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
-        default: write_features<NW, false, true>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
+        case 0: write_features<NW, true, false>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1, P.stamps); break;
+        case 1: write_features<NW, false, false>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1, P.stamps); break;
+        case 2: write_features<NW, true, true>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1, P.stamps); break;
+        default: write_features<NW, false, true>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1, P.stamps); break;
       }
     }
     STAMP(5);

@@ -924,7 +924,7 @@ __device__ __forceinline__ void write_features(BoardLds<NW>& L, const Geo<NW>& g
   }
   FSTAMP(15);
   WSYNC();
-  FSTAMP(7);
+  FSTAMP(11);
   // planes 14 / 15 straight from the distance tables (already in output order)
   if (g.wave == 0 || (NW > 1 && g.wave == 1)) {
     const bool second = NW > 1 && g.wave == 1;                       // wave 1 takes plane 15

@@ -47,6 +47,13 @@ for i, k in enumerate([1, 2, 3, 4, 5, 6, 7]):
     print("  %-14s %9.0f  (%.1f%%)" % (names[k], med[i].item(), 100 * med[i].item() / med.sum().item()))
 print("  total median %.0f  max %.0f" % (tot.median().item(), tot.max().item()))
 print("  grid span (last end - first start): %d" % int(s[:, 7].max() - s[:, 0].min()))
+# inside write_features (slots 13, 14, 15, 11), both recorded waves, cycles after stamp 4 of wave 0
+for w in (0, 1):
+    base = s[:, 4].double()
+    row = ["%s %6.0f" % (nm, (s[:, 16 * w + k].double() - base).median().item())
+           for nm, k in (("enter", 4), ("descriptors", 13), ("barrier 1", 14), ("distance / planes issued", 15),
+                         ("barrier 2", 11), ("planes 14/15 issued", 5), ("masks", 6), ("record + legal", 7))]
+    print("  wave %d, cycles after wave 0 entered write_features: %s" % (w, " | ".join(row)))
 starts = (s[:, 0] - s[:, 0].min()).double()
 print("  workgroup start times (cycles after the first): median %.0f  p90 %.0f  max %.0f" % (
     starts.median().item(), starts.quantile(0.9).item(), starts.max().item()))
