@@ -150,6 +150,21 @@ struct Slot {
   void* p = nullptr;
   size_t bytes = 0;
   bool device = false;
+  int T = 1;            // history entries the tensor holds ([T, B, ...], elf/state_collector.h:125-131)
+  size_t row = 0;       // bytes of one sample of this key
+};
+
+// CondPerGroupT (elf/comm_template.h:56-92): per game and exclusive group, when the group last took
+// a sample of the game.
+struct CondState {
+  int last_used_seq = 0, last_seq = 0, game_counter = 0;
+};
+
+// The host-kept part of one entry of a game's history (HistT<GameState>, elf/hist.h:19-66); planes,
+// mask and replies of the entry live in the device rings.
+struct HistEntry {
+  int32_t meta[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // kMetaKeys order
+  std::vector<int64_t> offline_a;
 };
 
 struct Collector {
@@ -226,9 +241,9 @@ class GameContext {
   int AddCollectors(int batchsize, int exclusive_id, int timeout_usec, const GroupStat& gstat) {
     if (started_) throw std::range_error("AddCollectors after Start()");
     if (batchsize <= 0) throw std::range_error("AddCollectors: batchsize must be positive");
-    if (gstat.hist_len != 1)
-      throw std::range_error("AddCollectors: hist_len " + std::to_string(gstat.hist_len) +
-                             " -- the device collector keeps T = 1 (what the Go scripts use)");
+    if (gstat.hist_len < 1 || gstat.hist_len > std::max(1, co_.T))
+      throw std::range_error("AddCollectors: hist_len " + std::to_string(gstat.hist_len) + " outside 1..ContextOptions.T = " +
+                             std::to_string(std::max(1, co_.T)) + " (a game keeps T entries: the group would never get a sample)");
     if (exclusive_id < 0 || exclusive_id > (int)groups_.size())
       throw std::range_error("AddCollectors: exclusive_id out of order");
     std::unique_ptr<Collector> c(new Collector());
@@ -287,14 +302,18 @@ class GameContext {
     const KeySpec* k = find_key(e.key);
     if (!k) throw std::range_error("AddTensor: unknown key \"" + e.key + "\"");
     const size_t inner = k->inner == -1 ? (size_t)opt_.num_future_actions : (size_t)k->inner;
-    const size_t want = (size_t)c.batchsize * inner * (size_t)k->elem;  // T = 1
-    if (e.p == 0 || e.byte_size != want)
-      throw std::range_error("AddTensor: \"" + e.key + "\" needs a buffer of " + std::to_string(want) +
-                             " bytes, got " + std::to_string(e.byte_size));
+    const size_t row = inner * (size_t)k->elem;
+    const size_t want = (size_t)c.batchsize * row;  // per history entry
+    const size_t T = want ? e.byte_size / want : 0;
+    if (e.p == 0 || T < 1 || T * want != e.byte_size || (int)T > std::max(1, co_.T))
+      throw std::range_error("AddTensor: \"" + e.key + "\" needs a buffer of T x " + std::to_string(want) +
+                             " bytes with T in 1..ContextOptions.T, got " + std::to_string(e.byte_size));
     Slot s;
     s.p = reinterpret_cast<void*>(e.p);
     s.bytes = e.byte_size;
     s.device = goenv_pointer_is_device(s.p) != 0;
+    s.T = (int)T;
+    s.row = row;
     (*dst)[e.key] = s;
   }
 
@@ -334,6 +353,7 @@ class GameContext {
       }
     }
     for (auto& g : groups_) { g.ready.clear(); g.stamp.clear(); }
+    setup_general();
     const uint64_t base_seed = opt_.seed ? (uint64_t)opt_.seed : clock_seed();
     for (int g = 0; g < co_.num_games; ++g) {
       GameSlot& gs = games_[g];
@@ -352,9 +372,19 @@ class GameContext {
         }
       }
       gs.phase = (opt_.mode == "online" && group_of("human_actor") >= 0) ? 0 : 1;
-      produce_sample(g);
+      if (general_) {
+        gs.cond.assign(groups_.size(), CondState());
+        gs.hist.assign(hist_T_, HistEntry());
+      } else {
+        produce_sample(g);
+      }
     }
     started_ = true;
+    if (general_) {
+      std::vector<int> all(co_.num_games);
+      for (int g = 0; g < co_.num_games; ++g) all[g] = g;
+      produce_general(all);
+    }
     finalize_searches();
   }
 
@@ -364,7 +394,11 @@ class GameContext {
       try { env_->sync(); } catch (...) {}
     }
     for (auto& c : collectors_) { c->busy = false; c->prefilled = false; c->games.clear(); c->release_buffers(); }
-    for (DevBuf* b : {&ts_src_, &ts_dst_, &ts_act_, &ts_status_, &ts_topa_, &ts_topp_, &ts_v_}) b->release();
+    for (DevBuf* b : {&ts_src_, &ts_dst_, &ts_act_, &ts_status_, &ts_topa_, &ts_topp_, &ts_v_, &g_rows_, &g_stage_s_,
+                      &g_stage_l_, &g_stage_, &g_idx_, &g_act_, &g_pi_, &g_status_})
+      b->release();
+    for (auto& kv : ring_) kv.second.release();
+    ring_.clear();
     games_.clear();
     searches_.clear();
     finished_.clear();
@@ -393,6 +427,10 @@ class GameContext {
     if (infos.gid < 0) return;  // timed-out Wait: nothing to release (comm_template.h:270)
     Collector& c = collector(infos.gid);
     if (!c.busy) throw std::range_error("Steps(): collector " + std::to_string(infos.gid) + " has no batch outstanding");
+    if (general_) {
+      steps_general(c);
+      return;
+    }
     bool fused = false;
     if (offline_) steps_offline(c);
     else if (leaf_batch(c)) steps_mcts(c);
@@ -485,6 +523,11 @@ class GameContext {
     std::vector<LeafRequest> requests;  // tree search: the outstanding leaf of every search thread
     int last_move = -3;                 // tree search: the move the last finished search played
     long moves_played = 0;
+    // general path (histories, several groups per sample)
+    std::vector<HistEntry> hist;        // ring of ContextOptions.T entries
+    int hist_head = -1, hist_size = 0;
+    std::vector<CondState> cond;        // per exclusive group
+    int pending = 0;                    // groups that still hold the game's newest sample
   };
   struct Group {
     std::string name;
@@ -515,6 +558,12 @@ class GameContext {
   std::mt19937 pick_rng_;
   DevBuf ts_src_, ts_dst_, ts_act_, ts_status_, ts_topa_, ts_topp_, ts_v_;
   WorkerPool pool_;             // host threads for per-game work between two device batches
+  // general path: a game keeps a history of hist_T_ samples (planes, mask, replies in device rings of
+  // [num_games x hist_T_] rows, labels on the host) and a sample may go to several exclusive groups
+  bool general_ = false;
+  int hist_T_ = 1;
+  std::map<std::string, DevBuf> ring_;   // key -> ring (s, legal, pi, a, V)
+  DevBuf g_rows_, g_stage_s_, g_stage_l_, g_stage_, g_idx_, g_act_, g_pi_, g_status_;
 
   static uint64_t clock_seed() {
     using namespace std::chrono;
@@ -678,7 +727,8 @@ class GameContext {
     c.games.assign(grp.ready.begin(), grp.ready.begin() + n);
     grp.ready.erase(grp.ready.begin(), grp.ready.begin() + n);
     grp.stamp.erase(grp.stamp.begin(), grp.stamp.begin() + n);
-    fill_inputs(c);
+    if (general_) fill_inputs_general(c);
+    else fill_inputs(c);
     c.busy = true;
     c.batches += 1;
     c.samples += n;
@@ -976,6 +1026,331 @@ class GameContext {
       ts.advance(&next[i]);
     });
     for (size_t i = 0; i < touched.size(); ++i) queue_leaves(touched[i], next[i]);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // General path: history length T > 1 and samples that several exclusive groups take
+  // (HistT elf/hist.h:19-66, CondPerGroupT::Check and SendDataWaitReply elf/comm_template.h:68-91,
+  // 215-261, CopyToMem / CopyFromMem elf/hist.h:71-121).  The plain Go topologies (every group T = 1,
+  // one group per sample name) never come here.
+  // ------------------------------------------------------------------------------------------
+  static bool ring_key(const std::string& k) { return k == "s" || k == "legal" || k == "pi" || k == "a" || k == "V"; }
+
+  std::vector<std::string> possible_names() const {
+    if (offline_) return {""};
+    if (opt_.mode == "online") return {"human_actor", "actor"};
+    return {"actor"};
+  }
+
+  void setup_general() {
+    general_ = false;
+    hist_T_ = std::max(1, co_.T);
+    for (const auto& c : collectors_) {
+      if (c->gstat.hist_len > 1) general_ = true;
+      for (const auto* m : {&c->input, &c->reply})
+        for (const auto& kv : *m)
+          if (kv.second.T > 1) general_ = true;
+    }
+    for (const std::string& name : possible_names()) {
+      int takers = 0;
+      for (const Group& g : groups_) takers += g.name.empty() || g.name == name;
+      if (takers > 1) general_ = true;
+    }
+    if (!general_) return;
+    if (mcts_) throw std::range_error("Start(): use_mcts with hist_len > 1 or several groups per sample is not supported");
+    const size_t rows = (size_t)co_.num_games * hist_T_;
+    for (const auto& c : collectors_)
+      for (const auto* m : {&c->input, &c->reply})
+        for (const auto& kv : *m)
+          if (ring_key(kv.first)) ring_[kv.first].ensure(env_->ctx(), rows * kv.second.row);
+  }
+
+  int ring_row(const GameSlot& gs, int g, int back) const {
+    if (back >= gs.hist_size) back = gs.hist_size - 1;   // "fill them with the oldest hist", elf/hist.h:90-98
+    return g * hist_T_ + (gs.hist_head - back + 2 * hist_T_) % hist_T_;
+  }
+
+  int board_of_game(const GameSlot& gs, int g) const {
+    return offline_ ? gs.loaders[gs.sample.loader]->board() : g;
+  }
+
+  // AI::Act up to SendDataWaitReply for every game of the list: Prepare pushes a history entry, extract
+  // fills it (labels on the host, planes and mask into the device rings in ONE launch for the whole
+  // list), then the sample is offered to every exclusive group.  A sample that no group takes (the
+  // history gate) lets the game act at once, as the reference does -- hence the loop.
+  void produce_general(std::vector<int> games) {
+    const int k = opt_.num_future_actions;
+    while (!games.empty()) {
+      const int m = (int)games.size();
+      std::vector<int32_t> boards(m), augs(m, 0), rows(m);
+      for (int i = 0; i < m; ++i) {
+        const int g = games[i];
+        GameSlot& gs = games_[g];
+        if (offline_) {
+          gs.sample.loader = (int)(gs.rng() % gs.loaders.size());  // go/game.cc:96
+          if (gs.loaders[gs.sample.loader]->just_started()) {      // before_act -> AIComm::Restart
+            gs.seq.seq = 0; gs.seq.game_counter += 1; gs.seq.last_terminal = 1;
+          }
+        }
+        gs.hist_head = (gs.hist_head + 1) % hist_T_;               // HistT::Prepare -> GetRoom
+        gs.hist_size = std::min(gs.hist_size + 1, hist_T_);
+        HistEntry& e = gs.hist[gs.hist_head];
+        e.meta[0] = g; e.meta[1] = gs.seq.seq; e.meta[2] = gs.seq.game_counter; e.meta[3] = gs.seq.last_terminal;
+        gs.seq.seq += 1; gs.seq.last_terminal = 0;                 // SeqInfo::Inc
+        e.offline_a.assign(k, 0);
+        if (offline_) {                                            // offpolicy_loader.cc:128-145
+          OfflineLoader& ld = *gs.loaders[gs.sample.loader];
+          e.meta[7] = ld.curr_game(); e.meta[4] = ld.ply(); e.meta[5] = ld.winner_label();
+          gs.sample.aug = ld.draw_aug_code();
+          e.meta[6] = gs.sample.aug;
+          ld.future_actions(gs.sample.aug, e.offline_a.data());
+        } else {                                                   // go/go_ai.h:79-87,106-113
+          gs.sample.aug = 0;
+          e.meta[4] = gs.ply; e.meta[5] = 0; e.meta[6] = 0; e.meta[7] = -1;
+        }
+        boards[i] = board_of_game(gs, g);
+        augs[i] = gs.sample.aug;
+        rows[i] = g * hist_T_ + gs.hist_head;
+      }
+      // extract: planes and mask of all listed boards -> staging rows -> their ring rows
+      const bool want_s = ring_.count("s") != 0, want_l = ring_.count("legal") != 0;
+      if (want_s || want_l) {
+        g_idx_.ensure(env_->ctx(), (size_t)m * 4); g_rows_.ensure(env_->ctx(), (size_t)m * 4); g_act_.ensure(env_->ctx(), (size_t)m * 8);
+        env_->h2d(g_idx_.get(), boards.data(), (size_t)m * 4);
+        env_->h2d(g_rows_.get(), rows.data(), (size_t)m * 4);
+        env_->h2d(g_act_.get(), augs.data(), (size_t)m * 4);
+        if (want_s) g_stage_s_.ensure(env_->ctx(), (size_t)m * GOENV_FEAT_FLOATS * 4);
+        if (want_l) g_stage_l_.ensure(env_->ctx(), (size_t)m * GOENV_NUM_POINTS);
+        chk(goenv_collect_sel(env_->ctx(), g_idx_.as<int32_t>(), 0, m, g_act_.as<int32_t>(),
+                              want_s ? g_stage_s_.as<float>() : nullptr, want_l ? g_stage_l_.as<uint8_t>() : nullptr, nullptr,
+                              env_->stream()), "goenv_collect_sel");
+        if (want_s)
+          chk(goenv_copy_rows(env_->ctx(), g_stage_s_.get(), nullptr, ring_["s"].get(), g_rows_.as<int32_t>(), m,
+                              (size_t)GOENV_FEAT_FLOATS * 4, env_->stream()), "goenv_copy_rows");
+        if (want_l)
+          chk(goenv_copy_rows(env_->ctx(), g_stage_l_.get(), nullptr, ring_["legal"].get(), g_rows_.as<int32_t>(), m,
+                              (size_t)GOENV_NUM_POINTS, env_->stream()), "goenv_copy_rows");
+      }
+      // SendDataWaitReply: one taker per exclusive group whose name and history gate pass
+      std::vector<int> free_to_act;
+      for (int g : games)
+        if (route(g) == 0) free_to_act.push_back(g);
+      if (!free_to_act.empty()) act_general(free_to_act);
+      games.swap(free_to_act);
+    }
+  }
+
+  int route(int g) {
+    GameSlot& gs = games_[g];
+    const std::string name = sample_name(gs);
+    const HistEntry& e = gs.hist[gs.hist_head];
+    int sent = 0;
+    for (size_t i = 0; i < groups_.size(); ++i) {
+      const GroupStat& st = collectors_[groups_[i].members[0]]->gstat;
+      if (!st.name.empty() && st.name != name) continue;           // check_name, comm_template.h:46-54
+      CondState& cs = gs.cond[i];
+      if (e.meta[2] > cs.game_counter) {                           // a new game: no frame is missed, :78-83
+        cs.game_counter = e.meta[2];
+        cs.last_used_seq -= cs.last_seq + 1;
+      }
+      cs.last_seq = e.meta[1];
+      if (gs.hist_size < st.hist_len || e.meta[1] - cs.last_used_seq < st.hist_len - 1) continue;   // :88, overlap 1
+      cs.last_used_seq = e.meta[1];
+      enqueue((int)i, g * tick_);
+      ++sent;
+    }
+    gs.pending = sent;
+    return sent;
+  }
+
+  // handle_response + forward for games whose every taker is done (or that had none)
+  void act_general(const std::vector<int>& games) {
+    const int m = (int)games.size();
+    if (offline_) {   // OfflineLoader::handle_response -> next(), batched as in steps_offline
+      std::vector<int32_t> boards;
+      std::vector<int64_t> acts;
+      std::vector<OfflineLoader*> who;
+      for (int g : games) {
+        GameSlot& gs = games_[g];
+        OfflineLoader* ld = gs.loaders[gs.sample.loader].get();
+        const int a = ld->begin_next();
+        if (a == -100) continue;
+        boards.push_back(ld->board());
+        acts.push_back(a);
+        who.push_back(ld);
+      }
+      const int n = (int)boards.size();
+      if (n == 0) return;
+      g_idx_.ensure(env_->ctx(), (size_t)n * 4); g_act_.ensure(env_->ctx(), (size_t)n * 8); g_status_.ensure(env_->ctx(), (size_t)n * 4);
+      env_->h2d(g_idx_.get(), boards.data(), (size_t)n * 4);
+      env_->h2d(g_act_.get(), acts.data(), (size_t)n * 8);
+      chk(goenv_ply_sel(env_->ctx(), g_idx_.as<int32_t>(), 0, n, 0u, g_act_.as<int64_t>(), nullptr, nullptr, nullptr, nullptr,
+                        nullptr, g_status_.as<int32_t>(), env_->stream()), "goenv_ply_sel");
+      std::vector<int32_t> st(n);
+      env_->d2h(st.data(), g_status_.get(), (size_t)n * 4);
+      env_->sync();
+      for (int i = 0; i < n; ++i) who[i]->end_next(st[i] == 1);
+      return;
+    }
+    // play modes: the move is the newest history entry's reply -- `a` if a collector replies it, else
+    // sampled from `pi` over the legal points
+    const bool have_a = ring_.count("a") != 0, have_pi = ring_.count("pi") != 0;
+    if (!have_a && !have_pi)
+      throw std::range_error("no collector replies \"a\" or \"pi\": the games cannot move");
+    std::vector<int32_t> boards(m), rows(m);
+    int human = 0;
+    for (int i = 0; i < m; ++i) {
+      const GameSlot& gs = games_[games[i]];
+      if (gs.pending != 0 || gs.hist_size == 0) throw std::range_error("internal: a game acts while its sample is still out");
+      boards[i] = games[i];
+      rows[i] = games[i] * hist_T_ + gs.hist_head;
+      human += gs.phase == 0;
+    }
+    g_idx_.ensure(env_->ctx(), (size_t)m * 4); g_rows_.ensure(env_->ctx(), (size_t)m * 4);
+    g_act_.ensure(env_->ctx(), (size_t)m * 8); g_status_.ensure(env_->ctx(), (size_t)m * 4);
+    env_->h2d(g_idx_.get(), boards.data(), (size_t)m * 4);
+    env_->h2d(g_rows_.get(), rows.data(), (size_t)m * 4);
+    if (have_a) {
+      chk(goenv_copy_rows(env_->ctx(), ring_["a"].get(), g_rows_.as<int32_t>(), g_act_.get(), nullptr, m, 8, env_->stream()),
+          "goenv_copy_rows");
+    } else {
+      g_pi_.ensure(env_->ctx(), (size_t)m * GOENV_NUM_POINTS * 4);
+      chk(goenv_copy_rows(env_->ctx(), ring_["pi"].get(), g_rows_.as<int32_t>(), g_pi_.get(), nullptr, m,
+                          (size_t)GOENV_NUM_POINTS * 4, env_->stream()), "goenv_copy_rows");
+      chk(goenv_sample_policy(env_->ctx(), g_idx_.as<int32_t>(), 0, m, g_pi_.as<float>(), nullptr, g_act_.as<int64_t>(),
+                              env_->stream()), "goenv_sample_policy");
+    }
+    const bool online = opt_.mode == "online";
+    uint32_t flags = 0;
+    if (!(online && human)) flags |= GOENV_F_RESET_ILLEGAL;
+    if (opt_.end_on_two_passes || opt_.ply_cap > 0) flags |= GOENV_F_RESTART_AFTER_END;
+    chk(goenv_ply_sel(env_->ctx(), g_idx_.as<int32_t>(), 0, m, flags, g_act_.as<int64_t>(), nullptr, nullptr, nullptr, nullptr,
+                      nullptr, g_status_.as<int32_t>(), env_->stream()), "goenv_ply_sel");
+    std::vector<int32_t> st(m);
+    env_->d2h(st.data(), g_status_.get(), (size_t)m * 4);
+    env_->sync();
+    const bool has_human = online && group_of("human_actor") >= 0 && groups_[group_of("human_actor")].name == "human_actor";
+    for (int i = 0; i < m; ++i) {
+      GameSlot& gs = games_[games[i]];
+      const bool restarted = st[i] == 2 || (st[i] == 0 && (flags & GOENV_F_RESET_ILLEGAL));
+      if (gs.phase == 0) {                    // a human's move: asked again when illegal
+        if (st[i] == 1) { gs.ply += 1; gs.phase = 1; }
+        else if (restarted) gs.ply = 1;
+        continue;
+      }
+      if (st[i] == 1) gs.ply += 1;
+      else gs.ply = 1;
+      if (restarted && opt_.signal_restart) {  // AICommT::Restart, elf/ai_comm.h:91-95
+        gs.seq.seq = 0; gs.seq.game_counter += 1; gs.seq.last_terminal = 1;
+      }
+      if (has_human) gs.phase = 0;
+    }
+  }
+
+  // row lists of one tensor: entry t of row r <- history entry (T - 1 - t) back from the newest
+  void window_rows(const Collector& c, int T, std::vector<int32_t>* hist_rows, std::vector<int32_t>* tensor_rows) const {
+    const int n = (int)c.games.size();
+    hist_rows->resize((size_t)T * n);
+    tensor_rows->resize((size_t)T * n);
+    for (int t = 0; t < T; ++t)
+      for (int r = 0; r < n; ++r) {
+        const int g = c.games[r] / tick_;
+        (*hist_rows)[(size_t)t * n + r] = ring_row(games_[g], g, T - 1 - t);
+        (*tensor_rows)[(size_t)t * n + r] = t * c.batchsize + r;
+      }
+  }
+
+  // CopyToMem (elf/hist.h:71-100): every registered input key, time-major, oldest entry first
+  void fill_inputs_general(Collector& c) {
+    const int n = (int)c.games.size();
+    c.boards.assign(n, 0);
+    bool need_sync = false;
+    std::vector<int32_t> hrows, trows;
+    for (auto& kv : c.input) {
+      const std::string& key = kv.first;
+      Slot& sl = kv.second;
+      const int T = sl.T;
+      window_rows(c, T, &hrows, &trows);
+      const size_t cnt = hrows.size();
+      if (ring_key(key)) {
+        g_rows_.ensure(env_->ctx(), cnt * 8);
+        env_->h2d(g_rows_.get(), hrows.data(), cnt * 4);
+        env_->h2d(g_rows_.as<int32_t>() + cnt, trows.data(), cnt * 4);
+        void* dst = sl.p;
+        if (!sl.device) {
+          g_stage_.ensure(env_->ctx(), sl.bytes);
+          dst = g_stage_.get();
+        }
+        chk(goenv_copy_rows(env_->ctx(), ring_[key].get(), g_rows_.as<int32_t>(), dst, g_rows_.as<int32_t>() + cnt, (int)cnt,
+                            sl.row, env_->stream()), "goenv_copy_rows");
+        if (!sl.device) {   // only the rows of this batch reach the caller's buffer
+          for (int t = 0; t < T; ++t)
+            env_->d2h((char*)sl.p + (size_t)t * c.batchsize * sl.row, (char*)dst + (size_t)t * c.batchsize * sl.row, (size_t)n * sl.row);
+          env_->sync();     // the staging buffer is reused by the next key
+          need_sync = false;
+        }
+        continue;
+      }
+      // host-kept keys: the eight labels and offline_a
+      int mk = -1;
+      for (int i = 0; i < 8; ++i)
+        if (key == kMetaKeys[i]) mk = i;
+      std::vector<char> buf((size_t)n * sl.row);
+      for (int t = 0; t < T; ++t) {
+        for (int r = 0; r < n; ++r) {
+          const int g = c.games[r] / tick_;
+          const GameSlot& gs = games_[g];
+          const HistEntry& e = gs.hist[ring_row(gs, g, T - 1 - t) - g * hist_T_];
+          char* out = buf.data() + (size_t)r * sl.row;
+          if (mk == 3) { const int8_t v = (int8_t)e.meta[3]; std::memcpy(out, &v, 1); }
+          else if (mk >= 0) std::memcpy(out, &e.meta[mk], 4);
+          else if (key == "offline_a") std::memcpy(out, e.offline_a.data(), sl.row);
+          else std::memset(out, 0, sl.row);
+        }
+        char* dst = (char*)sl.p + (size_t)t * c.batchsize * sl.row;
+        if (sl.device) { env_->h2d(dst, buf.data(), buf.size()); need_sync = true; }
+        else std::memcpy(dst, buf.data(), buf.size());
+      }
+    }
+    if (need_sync) env_->sync();   // `buf` above is pageable host memory: be done with it before it goes
+  }
+
+  // CopyFromMem (elf/hist.h:102-121) of the reply keys into the games' histories, then every game whose
+  // takers are all done acts and offers its next sample
+  void steps_general(Collector& c) {
+    const int n = (int)c.games.size();
+    std::vector<int32_t> hrows, trows;
+    for (auto& kv : c.reply) {
+      if (!ring_key(kv.first)) continue;
+      Slot& sl = kv.second;
+      window_rows(c, sl.T, &hrows, &trows);
+      const size_t cnt = hrows.size();
+      g_rows_.ensure(env_->ctx(), cnt * 8);
+      env_->h2d(g_rows_.get(), hrows.data(), cnt * 4);
+      env_->h2d(g_rows_.as<int32_t>() + cnt, trows.data(), cnt * 4);
+      const void* src = sl.p;
+      if (!sl.device) {
+        g_stage_.ensure(env_->ctx(), sl.bytes);
+        env_->h2d(g_stage_.get(), sl.p, sl.bytes);
+        src = g_stage_.get();
+      }
+      chk(goenv_copy_rows(env_->ctx(), src, g_rows_.as<int32_t>() + cnt, ring_[kv.first].get(), g_rows_.as<int32_t>(), (int)cnt,
+                          sl.row, env_->stream()), "goenv_copy_rows");
+      if (!sl.device) env_->sync();
+    }
+    std::vector<int> released;
+    for (int ticket : c.games) {
+      GameSlot& gs = games_[ticket / tick_];
+      if (--gs.pending == 0) released.push_back(ticket / tick_);
+    }
+    c.busy = false;
+    c.games.clear();
+    c.boards.clear();
+    (void)n;
+    if (!released.empty()) {
+      act_general(released);
+      produce_general(released);
+    }
   }
 
   // offline: OfflineLoader::handle_response -> next() for every sample of the batch

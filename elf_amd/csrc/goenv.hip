@@ -774,6 +774,26 @@ __global__ __launch_bounds__(128) void k_copy_boards(BoardRec* state, int n_tota
   for (int i = threadIdx.x; i < (int)(sizeof(BoardRec) / 16); i += blockDim.x) out[i] = in[i];
 }
 
+// Row gather / scatter between two row-major tables: row dst_rows[i] of dst <- row src_rows[i] of src
+// (NULL list: row i).  The device form of the collector's per-key memcpy (elf/copier.hh:97-101) between
+// a game's history and a batch tensor.  Dword copies when both rows are 4-byte aligned, bytes otherwise.
+__global__ __launch_bounds__(256) void k_copy_rows(const unsigned char* src, const int32_t* src_rows, unsigned char* dst,
+                                                   const int32_t* dst_rows, int n, size_t row_bytes) {
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  const long long sr = src_rows ? src_rows[i] : i, dr = dst_rows ? dst_rows[i] : i;
+  if (sr < 0 || dr < 0) return;
+  const unsigned char* a = src + (size_t)sr * row_bytes;
+  unsigned char* b = dst + (size_t)dr * row_bytes;
+  if ((((uintptr_t)a | (uintptr_t)b | row_bytes) & 3) == 0) {
+    const uint32_t* a4 = reinterpret_cast<const uint32_t*>(a);
+    uint32_t* b4 = reinterpret_cast<uint32_t*>(b);
+    for (size_t k = threadIdx.x; k < row_bytes / 4; k += blockDim.x) b4[k] = a4[k];
+  } else {
+    for (size_t k = threadIdx.x; k < row_bytes; k += blockDim.x) b[k] = a[k];
+  }
+}
+
 // The k legal points of largest policy weight, in descending order: what DirectPredictAI::get_last_pi
 // (go/go_ai.h:24-68) hands to the tree search (it sorts all 361 by pi and keeps the first five that
 // pass CheckMove).  One wavefront per board; k rounds of a wave-wide arg-max over the legal
@@ -1468,6 +1488,19 @@ int goenv_copy_boards(goenv_ctx* c, const int32_t* src_idx, const int32_t* dst_i
   if (n == 0) return 0;
   if (!src_idx || !dst_idx) return fail("goenv_copy_boards: src_idx and dst_idx are required");
   hipLaunchKernelGGL(k_copy_boards, dim3(n), dim3(128), 0, S(stream), c->state, c->n, src_idx, dst_idx, n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int goenv_copy_rows(goenv_ctx* c, const void* src, const int32_t* src_rows, void* dst, const int32_t* dst_rows, int n,
+                    size_t row_bytes, void* stream) {
+  if (!c) return fail("goenv_copy_rows: ctx is NULL");
+  if (n < 0 || row_bytes == 0) return fail("goenv_copy_rows: n must be >= 0 and row_bytes positive");
+  if (n == 0) return 0;
+  if (!src || !dst) return fail("goenv_copy_rows: src and dst are required");
+  ON_DEVICE_OF(c);
+  hipLaunchKernelGGL(k_copy_rows, dim3(n), dim3(256), 0, S(stream), (const unsigned char*)src, src_rows,
+                     (unsigned char*)dst, dst_rows, n, row_bytes);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -63,6 +63,8 @@ _SIGS = {
     "goenv_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "goenv_host_free": (C.c_int, [C.c_void_p]),
     "goenv_copy_boards": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "goenv_copy_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t,
+                                  C.c_void_p]),
     "goenv_pointer_is_device": (C.c_int, [C.c_void_p]),
     "goenv_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "goenv_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -349,6 +351,22 @@ class GoEnv:
         self._check(src_idx, torch.int32, (n,), "src_idx")
         self._check(dst_idx, torch.int32, (n,), "dst_idx")
         self._chk(self.lib.goenv_copy_boards(self._h, _ptr(src_idx), _ptr(dst_idx), n, self._stream()))
+
+    def copy_rows(self, src, dst, src_rows=None, dst_rows=None, n=None):
+        """goenv_copy_rows between two contiguous tensors whose rows ([rows, ...]) have the same byte size."""
+        rb = src[0].numel() * src.element_size()
+        if not (src.is_contiguous() and dst.is_contiguous()) or dst[0].numel() * dst.element_size() != rb:
+            raise GoEnvError("copy_rows: contiguous tensors with rows of equal byte size are required")
+        for t, rows in ((src_rows, src.shape[0]), (dst_rows, dst.shape[0])):
+            if t is not None:
+                self._check(t, torch.int32, (t.numel(),), "row list")
+                if t.numel() and (int(t.max()) >= rows):
+                    raise GoEnvError("copy_rows: a row index exceeds the table")
+        if n is None:
+            n = src_rows.numel() if src_rows is not None else (dst_rows.numel() if dst_rows is not None else
+                                                               min(src.shape[0], dst.shape[0]))
+        self._chk(self.lib.goenv_copy_rows(self._h, _ptr(src), _ptr(src_rows), _ptr(dst), _ptr(dst_rows), int(n), rb,
+                                           self._stream()))
 
     def playout(self, moves_out=None, nmoves_out=None):
         max_record = 0

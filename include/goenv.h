@@ -320,6 +320,14 @@ int goenv_replay(goenv_ctx* ctx, const int32_t* idx, int first, int count, const
 int goenv_copy_boards(goenv_ctx* ctx, const int32_t* src_idx, const int32_t* dst_idx, int n,
                       void* stream);
 
+/* goenv_copy_rows: row dst_rows[i] of `dst` <- row src_rows[i] of `src`, i in [0, n), rows of row_bytes
+ * bytes in row-major tables on the context's device (a NULL list means row i; a negative row is
+ * skipped; destination rows must be distinct).  The per-key copy of the reference's collectors between
+ * a game's history and the batch memory (CopyToMem / CopyFromMem, elf/hist.h:71-121,
+ * elf/copier.hh:97-101), for histories that live on the device. */
+int goenv_copy_rows(goenv_ctx* ctx, const void* src, const int32_t* src_rows, void* dst,
+                    const int32_t* dst_rows, int n, size_t row_bytes, void* stream);
+
 /* Memory helpers for hosts that do not link the HIP runtime themselves (the
  * GameContext layer): pointer classification (EntryInfo.p may be host or
  * device, SURVEY 8b "Ownership"), stream-ordered copy in either direction,

@@ -134,6 +134,16 @@ RUNS_256 = [
          cutoff=-1, k=3, samples=12, lst="train.lst"),
 ]
 
+# History length T > 1 (elf/hist.h:19-66, gating elf/comm_template.h:68-91): every delivered row is
+# a window of the game thread's last T samples, oldest first, consecutive windows overlap by one.
+# `make_golden_batch.py --hist` writes batch_hist_streams.json (a stream entry = one window = T samples).
+RUNS_HIST = [
+    dict(name="hist3", T=3, seed=7, num_games=3, games_per_thread=2, data_aug=-1, start_ratio=0.5, ratio=0.0,
+         cutoff=-1, k=3, samples=60, lst="train.lst"),
+    dict(name="hist4_aug0", T=4, seed=11, num_games=2, games_per_thread=1, data_aug=0, start_ratio=0.9, ratio=0.3,
+         cutoff=40, k=3, samples=50, lst="train.lst"),
+]
+
 QUIRK_TEXTS = [
     "(;GM[1]SZ[19]RE[b+R]HA[4];B[pd];W[];B[tt];W[dd])", "(;GM[1];B[aa]\nW[bb];W[cc])",
     "(;GM[1];B[aa]C[x \\] ;B[bb] y];W[cc])", "(;GM[1];B[aa](;W[bb])(;W[cc]))", "(;GM[1];B[aa];(;W[bb]);W[cc])",
@@ -153,7 +163,8 @@ _KEEP_ALIVE = []
 def run_reference(go, cfg):
     co = go.ContextOptions()
     co.num_games = cfg["num_games"]
-    co.T = 1
+    T = cfg.get("T", 1)
+    co.T = T
     co.num_collectors = 1
     opt = go.GameOptions()
     opt.seed = cfg["seed"]
@@ -168,12 +179,12 @@ def run_reference(go, cfg):
     opt.verbose = False
     GC = go.GameContext(co, opt)
     gstat = GC.CreateGroupStat()
-    gstat.hist_len = 1
+    gstat.hist_len = T
     B = cfg["num_games"]
     gid = GC.AddCollectors(B, 0, 0, gstat)
     bufs = {}
     for key in KEYS:
-        info = GC.GetTensorSpec(gid, key, 1)
+        info = GC.GetTensorSpec(gid, key, T)
         assert info.key == key, key
         v = np.zeros(info.sz, dtype=NP_TYPES[info.type])
         info.p = v.ctypes.data
@@ -186,10 +197,12 @@ def run_reference(go, cfg):
         infos = GC.Wait(0)
         n = len(infos.s)
         for r in range(n):
-            g = int(bufs["id"][0, r])
-            streams[g].append([int(bufs[k][0, r]) for k in KEYS[2:]] +
-                              [[int(a) for a in bufs["offline_a"][0, r]]] +
-                              ["%016x" % fnv_planes(FNV_SEED, bufs["s"][0, r].reshape(-1))])
+            g = int(bufs["id"][T - 1, r])
+
+            def entry(t):
+                return ([int(bufs[k][t, r]) for k in KEYS[2:]] + [[int(a) for a in bufs["offline_a"][t, r]]] +
+                        ["%016x" % fnv_planes(FNV_SEED, bufs["s"][t, r].reshape(-1))])
+            streams[g].append(entry(0) if T == 1 else [entry(t) for t in range(T)])
         GC.Steps(infos)
     # no GC.Stop(): the reference's teardown blocks on its worker threads.  Its threads keep writing
     # into the buffers, so context and buffers stay alive until the caller (one process per
@@ -205,21 +218,24 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--run":     # child: one configuration, then leave hard
         sys.path.insert(0, os.path.dirname(so[0]))
         import go_game as go
-        st = run_reference(go, (RUNS + RUNS_256)[int(sys.argv[2])])
+        st = run_reference(go, (RUNS + RUNS_256 + RUNS_HIST)[int(sys.argv[2])])
         dump_json(sys.argv[3], st)
         sys.stdout.flush()
         os._exit(0)
     import subprocess
     import tempfile
-    if "--batch256" in sys.argv:                          # the corpus stays as committed
+    if "--batch256" in sys.argv or "--hist" in sys.argv:  # the corpus stays as committed
+        hist = "--hist" in sys.argv
+        runs, first = (RUNS_HIST, len(RUNS) + len(RUNS_256)) if hist else (RUNS_256, len(RUNS))
+        fname = "batch_hist_streams.json" if hist else "batch256_streams.json"
         with open(os.path.join(CORPUS, "train.lst")) as f:
             names = f.read().split()
         out = dict(corpus=names, fields=KEYS[2:] + ["offline_a", "s_fnv"], runs=[])
-        for i, cfg in enumerate(RUNS_256):
+        for i, cfg in enumerate(runs):
             with tempfile.TemporaryDirectory() as td:
                 tmp = os.path.join(td, "run.json")
                 for attempt in range(4):
-                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--run", str(len(RUNS) + i), tmp],
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--run", str(first + i), tmp],
                                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
                     if r.returncode == 0 and os.path.exists(tmp):
                         break
@@ -229,8 +245,8 @@ def main():
                     st = json.load(f)
             out["runs"].append(dict(cfg=cfg, streams=st))
             print(cfg["name"], len(st), "games x", cfg["samples"], "samples", flush=True)
-        dump_json(os.path.join(GOLDEN, "batch256_streams.json"), out)
-        print("written", os.path.join(GOLDEN, "batch256_streams.json"))
+        dump_json(os.path.join(GOLDEN, fname), out)
+        print("written", os.path.join(GOLDEN, fname))
         return
     names = make_corpus()
     # what the reference's Sgf::Load makes of every corpus file (oracle/_ref/libgoref.so)

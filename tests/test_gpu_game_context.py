@@ -306,3 +306,170 @@ def test_fused_selfplay_step_against_oracle(go, monkeypatch, N, B, ncoll, fuse_m
         gc.Stop()
         streams.append(rows)
     assert streams[0] == streams[1]
+
+
+@pytest.mark.parametrize("device", [False, True])
+def test_history_windows_equal_the_reference_module(go, device):
+    """History length T > 1 (elf/hist.h:19-66, gate elf/comm_template.h:68-91): every delivered row is the
+    window of the game's last T samples, oldest first, consecutive windows overlapping by one -- against
+    tests/golden/batch_hist_streams.json, recorded from the compiled reference module with ContextOptions.T =
+    GroupStat.hist_len = T and [T, B, ...] tensors."""
+    gold = load_golden("batch_hist_streams.json")
+    for run in gold["runs"]:
+        cfg = run["cfg"]
+        T, B = cfg["T"], cfg["num_games"]
+        co = go.ContextOptions()
+        co.num_games, co.T = B, T
+        opt = go.GameOptions()
+        opt.seed, opt.mode = cfg["seed"], "offline"
+        opt.list_filename = os.path.join(GOLDEN, "corpus", cfg["lst"])
+        opt.data_aug, opt.start_ratio_pre_moves, opt.ratio_pre_moves = cfg["data_aug"], cfg["start_ratio"], cfg["ratio"]
+        opt.move_cutoff, opt.num_games_per_thread, opt.num_future_actions = cfg["cutoff"], cfg["games_per_thread"], cfg["k"]
+        gc = go.GameContext(co, opt)
+        gs = gc.CreateGroupStat()
+        gs.hist_len = T
+        gid = gc.AddCollectors(B, 0, 0, gs)
+        bufs = {}
+        for key in ["s", "offline_a"] + LABELS:
+            info = gc.GetTensorSpec(gid, key, T)
+            assert info.sz[:2] == [T, B]
+            if device:
+                v = torch.zeros(*info.sz, dtype=TORCH_TYPES[info.type], device="cuda:0")
+                info.p, info.byte_size = v.data_ptr(), v.numel() * v.element_size()
+            else:
+                v = np.zeros(info.sz, dtype=NP_TYPES[info.type])
+                info.p, info.byte_size = v.ctypes.data, v.nbytes
+            gc.AddTensor(gid, "input", info)
+            bufs[key] = v
+        gc.Start()
+        n_check = min(cfg["samples"], 25 if device else cfg["samples"])
+        streams = {g: [] for g in range(B)}
+        while min(len(v) for v in streams.values()) < n_check:
+            infos = gc.Wait(0)
+            assert infos.gid == gid
+            h = {k: host(v) for k, v in bufs.items()}
+            for r in range(len(infos.s)):
+                g = int(h["id"][T - 1, r])
+                assert g == infos.s[r]
+                streams[g].append([[int(h[k][t, r]) for k in LABELS] + [[int(a) for a in h["offline_a"][t, r]]] +
+                                   ["%016x" % fnv_planes(FNV_SEED, h["s"][t, r].reshape(-1))] for t in range(T)])
+            gc.Steps(infos)
+        gc.Stop()
+        for g in range(B):
+            want, got = run["streams"][str(g)][:n_check], streams[g][:n_check]
+            for i, (a, b) in enumerate(zip(got, want)):
+                assert a == b, "run %s game %d window %d: got %s, reference %s" % (cfg["name"], g, i, a, b)
+
+
+def test_selfplay_sample_goes_to_an_actor_and_a_history_group(go):
+    """The RL-training topology of ELF (docs/source/wrapper-python.rst:38-65): every sample goes to the `actor`
+    group (T = 1, replies a) AND to an unnamed `train` group with history T = 4 (keys s, a, labels).  The
+    game moves only when both are done with it.  Train windows: T consecutive samples of one game, planes of
+    entry t = the oracle's at that time, a[t] = the action replied for that sample, windows overlap by one."""
+    N, B, T = 8, 8, 4
+    co = go.ContextOptions()
+    co.num_games, co.T = N, T
+    opt = go.GameOptions()
+    opt.mode, opt.seed = "selfplay", 3
+    gc = go.GameContext(co, opt)
+    ga = gc.CreateGroupStat()
+    ga.name = "actor"
+    gid_a = gc.AddCollectors(B, 0, 0, ga)
+    gt = gc.CreateGroupStat()
+    gt.hist_len = T
+    gid_t = gc.AddCollectors(B, 1, 0, gt)
+
+    def reg(gid, which, keys, T_):
+        out = {}
+        for key in keys:
+            info = gc.GetTensorSpec(gid, key, T_)
+            v = torch.zeros(*info.sz, dtype=TORCH_TYPES[info.type], device="cuda:0")
+            info.p, info.byte_size = v.data_ptr(), v.numel() * v.element_size()
+            gc.AddTensor(gid, which, info)
+            out[key] = v
+        return out
+
+    act_in = reg(gid_a, "input", ["s", "legal", "id", "seq"], 1)
+    act_out = reg(gid_a, "reply", ["a", "V"], 1)
+    tr_in = reg(gid_t, "input", ["s", "a", "id", "seq", "move_idx"], T)
+    gc.Start()
+    oracles = [OracleBoard() for _ in range(N)]
+    planes = {}                      # (game, seq) -> planes the oracle had when that sample was taken
+    action = {}                      # (game, seq) -> action replied
+    rng = np.random.RandomState(1)
+    windows = {g: [] for g in range(N)}
+    moved = [0] * N                  # moves applied = seq of the game's current sample
+    n_actor = n_train = 0
+    for it in range(60):
+        infos = gc.Wait(0)
+        assert infos.gid in (gid_a, gid_t)
+        if infos.gid == gid_a:
+            n_actor += 1
+            h = {k: v.cpu().numpy()[0] for k, v in act_in.items()}
+            acts = []
+            for r, g in enumerate(infos.s):
+                o = oracles[g]
+                assert h["id"][r] == g
+                seq = int(h["seq"][r])
+                assert_planes_equal(h["s"][r], o.extract(0), "actor game %d seq %d" % (g, seq))
+                planes[(g, seq)] = o.extract(0).copy()
+                legal = np.flatnonzero(o.legal())
+                a = int(legal[rng.randint(legal.size)])
+                action[(g, seq)] = a
+                acts.append(a)
+                assert o.forward(a)[0]
+                moved[g] += 1
+            act_out["a"].copy_(torch.tensor([acts], dtype=torch.int64))
+        else:
+            n_train += 1
+            h = {k: v.cpu().numpy() for k, v in tr_in.items()}
+            for r, g in enumerate(infos.s):
+                seqs = [int(h["seq"][t, r]) for t in range(T)]
+                assert seqs == list(range(seqs[0], seqs[0] + T)), seqs
+                assert all(int(h["id"][t, r]) == g for t in range(T))
+                for t in range(T):
+                    if (g, seqs[t]) not in planes:       # the train group got the newest sample before the actor did
+                        assert t == T - 1 and seqs[t] == moved[g]
+                        planes[(g, seqs[t])] = oracles[g].extract(0).copy()
+                    assert_planes_equal(h["s"][t, r], planes[(g, seqs[t])], "train game %d seq %d" % (g, seqs[t]))
+                    assert int(h["move_idx"][t, r]) == seqs[t] + 1
+                    if (g, seqs[t]) in action:   # the newest entry's action may not have been replied yet
+                        assert int(h["a"][t, r]) == action[(g, seqs[t])]
+                windows[g].append(seqs)
+        gc.Steps(infos)
+    gc.Stop()
+    assert n_train >= 10 and n_actor >= 3 * n_train - 3
+    for g in range(N):
+        w = windows[g]
+        assert w[0][0] == 0
+        for a, b in zip(w, w[1:]):
+            assert b[0] == a[-1], "windows of game %d do not overlap by one: %s %s" % (g, a, b)
+
+
+def test_gcwrapper_offline_with_history(go):
+    """train_df shape with --T 3 (the reference's ContextArgs default is T = 6, elf/context_utils.py:20):
+    batch.hist(t) is entry t of every row's window; consecutive entries are consecutive samples."""
+    from elf_amd import go_loader
+    args = go_loader.add_arguments().parse_args(
+        ["--mode", "offline", "--num_games", "4", "--batchsize", "4", "--T", "3", "--gpu", "0", "--seed", "7",
+         "--list_file", os.path.join(GOLDEN, "corpus", "train.lst"), "--num_games_per_thread", "1",
+         "--additional_labels", "id,seq,move_idx,game_record_idx"])
+    GC = go_loader.initialize(args)
+    seen = []
+
+    def train(batch):
+        assert tuple(batch["s"].shape) == (3, 4, 25, 19, 19)
+        seq = torch.stack([batch.hist(t)["seq"] for t in range(3)]).cpu()
+        assert torch.equal(seq[1], seq[0] + 1) and torch.equal(seq[2], seq[1] + 1)
+        rec = torch.stack([batch.hist(t)["game_record_idx"] for t in range(3)]).cpu()
+        mi = torch.stack([batch.hist(t)["move_idx"] for t in range(3)]).cpu()
+        same = rec[1] == rec[0]                      # same record: the next sample is one ply later
+        assert torch.equal(mi[1][same], mi[0][same] + 1)
+        seen.append(seq[2].tolist())
+
+    GC.reg_callback("train", train)
+    GC.Start()
+    for _ in range(12):
+        GC.Run()
+    GC.Stop()
+    assert len(seen) == 12 and seen[1][0] == seen[0][0] + 2      # windows advance by T - 1
