@@ -261,3 +261,50 @@ def test_copy_boards_branches_positions(goenv):
     with pytest.raises(goenv.GoEnvError):
         env.copy_boards(torch.zeros(B + 1, dtype=torch.int32, device=dev), torch.zeros(B + 1, dtype=torch.int32, device=dev))
     env.close()
+
+
+def test_restart_then_rejected_action_counts_the_game_once(goenv):
+    """A finished board under AUTO_RESTART is scored, counted and restarted BEFORE the external action is
+    validated; if the action is then rejected the restarted record must still be stored, or the next call
+    would count the same game again."""
+    env = goenv.GoEnv(4, seed=2, max_ply=722)
+    dev = env.device
+    two_passes = torch.full((4,), -1, dtype=torch.int64, device=dev)
+    env.ply(0, actions=two_passes)
+    env.ply(0, actions=two_passes)                      # every board: IsGameEnd
+    assert env.get_state()["scalars"][:, goenv.S_DONE].cpu().tolist() == [1, 1, 1, 1]
+    bad = torch.full((4,), 361, dtype=torch.int64, device=dev)      # out of range: rejected
+    status = env.new(torch.int32)
+    feat, legal = env.new(torch.float32, 25, 19, 19), env.new(torch.uint8, 361)
+    for _ in range(2):
+        env.ply(goenv.F_AUTO_RESTART, actions=bad, feat_out=feat, legal_out=legal, status_out=status)
+        assert status.cpu().tolist() == [0, 0, 0, 0]
+    st = env.stats()
+    assert st[goenv.ST_GAMES] == 4 and st[goenv.ST_PLIES] == 8
+    sc = env.get_state()["scalars"].cpu()
+    assert sc[:, goenv.S_DONE].tolist() == [0] * 4 and sc[:, goenv.S_PLY].tolist() == [1] * 4
+    assert sc[:, goenv.S_GAME].tolist() == [1] * 4
+    o = OracleBoard()                                    # what was written belongs to the restarted (empty) board
+    for b in range(4):
+        assert_planes_equal(feat[b].cpu().numpy(), o.extract(0), "board %d" % b)
+        assert np.array_equal(legal[b].cpu().numpy(), o.legal())
+    env.close()
+
+
+def test_copy_rows_gathers_and_scatters(goenv):
+    env = goenv.GoEnv(2, seed=1)
+    dev = env.device
+    for shape, dtype in (((40, 361), torch.uint8), ((40, 25, 19, 19), torch.float32), ((40,), torch.int64)):
+        src = (torch.rand(shape, device=dev) * 200).to(dtype)
+        dst = torch.zeros((25,) + shape[1:], dtype=dtype, device=dev)
+        sr = torch.tensor([3, 39, 0, 17, 3], dtype=torch.int32, device=dev)
+        dr = torch.tensor([24, 1, 7, 0, 9], dtype=torch.int32, device=dev)
+        env.copy_rows(src, dst, sr, dr)
+        want = torch.zeros_like(dst)
+        want[dr.long()] = src[sr.long()]
+        assert torch.equal(dst, want)
+        env.copy_rows(src, dst, None, None, n=25)        # identity lists
+        assert torch.equal(dst, src[:25])
+    with pytest.raises(goenv.GoEnvError):
+        env.copy_rows(torch.zeros(4, 8, device=dev), torch.zeros(4, 9, device=dev))
+    env.close()
