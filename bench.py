@@ -225,7 +225,8 @@ def main():
     out = {
         "metric": "19x19 Go moves/sec (node, 1/2/4/8 GPU) + feature-extract HBM GB/s",
         "value": value, "unit": "moves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed * 1e3 / args.steps, "moves_per_step": world * B * T,
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "i32", "data": "synthetic",
         "config": {"workload": "cfg2: %d concurrent 19x19 games per GPU, on-device uniform-random legal-move "
                                "playouts to the end (scored, counted, restarted in place); every ply of every "
