@@ -561,6 +561,7 @@ class GameContext {
   // general path: a game keeps a history of hist_T_ samples (planes, mask, replies in device rings of
   // [num_games x hist_T_] rows, labels on the host) and a sample may go to several exclusive groups
   bool general_ = false;
+  bool reply_a_ = false, reply_pi_ = false;   // some collector REPLIES the key (an input-only `a` is history, not a move)
   int hist_T_ = 1;
   std::map<std::string, DevBuf> ring_;   // key -> ring (s, legal, pi, a, V)
   DevBuf g_rows_, g_stage_s_, g_stage_l_, g_stage_, g_idx_, g_act_, g_pi_, g_status_;
@@ -1044,8 +1045,11 @@ class GameContext {
 
   void setup_general() {
     general_ = false;
+    reply_a_ = reply_pi_ = false;
     hist_T_ = std::max(1, co_.T);
     for (const auto& c : collectors_) {
+      reply_a_ |= c->reply.count("a") != 0;
+      reply_pi_ |= c->reply.count("pi") != 0;
       if (c->gstat.hist_len > 1) general_ = true;
       for (const auto* m : {&c->input, &c->reply})
         for (const auto& kv : *m)
@@ -1194,7 +1198,7 @@ class GameContext {
     }
     // play modes: the move is the newest history entry's reply -- `a` if a collector replies it, else
     // sampled from `pi` over the legal points
-    const bool have_a = ring_.count("a") != 0, have_pi = ring_.count("pi") != 0;
+    const bool have_a = reply_a_, have_pi = reply_pi_;
     if (!have_a && !have_pi)
       throw std::range_error("no collector replies \"a\" or \"pi\": the games cannot move");
     std::vector<int32_t> boards(m), rows(m);
@@ -1266,6 +1270,7 @@ class GameContext {
     c.boards.assign(n, 0);
     bool need_sync = false;
     std::vector<int32_t> hrows, trows;
+    std::vector<std::vector<char>> bufs;
     for (auto& kv : c.input) {
       const std::string& key = kv.first;
       Slot& sl = kv.second;
@@ -1295,30 +1300,31 @@ class GameContext {
       int mk = -1;
       for (int i = 0; i < 8; ++i)
         if (key == kMetaKeys[i]) mk = i;
-      std::vector<char> buf((size_t)n * sl.row);
+      bufs.emplace_back((size_t)T * n * sl.row);       // kept until the copies below have been waited for
+      std::vector<char>& buf = bufs.back();
       for (int t = 0; t < T; ++t) {
+        char* base = buf.data() + (size_t)t * n * sl.row;
         for (int r = 0; r < n; ++r) {
           const int g = c.games[r] / tick_;
           const GameSlot& gs = games_[g];
           const HistEntry& e = gs.hist[ring_row(gs, g, T - 1 - t) - g * hist_T_];
-          char* out = buf.data() + (size_t)r * sl.row;
+          char* out = base + (size_t)r * sl.row;
           if (mk == 3) { const int8_t v = (int8_t)e.meta[3]; std::memcpy(out, &v, 1); }
           else if (mk >= 0) std::memcpy(out, &e.meta[mk], 4);
           else if (key == "offline_a") std::memcpy(out, e.offline_a.data(), sl.row);
           else std::memset(out, 0, sl.row);
         }
         char* dst = (char*)sl.p + (size_t)t * c.batchsize * sl.row;
-        if (sl.device) { env_->h2d(dst, buf.data(), buf.size()); need_sync = true; }
-        else std::memcpy(dst, buf.data(), buf.size());
+        if (sl.device) { env_->h2d(dst, base, (size_t)n * sl.row); need_sync = true; }
+        else std::memcpy(dst, base, (size_t)n * sl.row);
       }
     }
-    if (need_sync) env_->sync();   // `buf` above is pageable host memory: be done with it before it goes
+    if (need_sync) env_->sync();   // `bufs` is pageable host memory: be done with it before it goes
   }
 
   // CopyFromMem (elf/hist.h:102-121) of the reply keys into the games' histories, then every game whose
   // takers are all done acts and offers its next sample
   void steps_general(Collector& c) {
-    const int n = (int)c.games.size();
     std::vector<int32_t> hrows, trows;
     for (auto& kv : c.reply) {
       if (!ring_key(kv.first)) continue;
@@ -1346,7 +1352,6 @@ class GameContext {
     c.busy = false;
     c.games.clear();
     c.boards.clear();
-    (void)n;
     if (!released.empty()) {
       act_general(released);
       produce_general(released);
