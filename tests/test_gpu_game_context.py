@@ -473,3 +473,44 @@ def test_gcwrapper_offline_with_history(go):
         GC.Run()
     GC.Stop()
     assert len(seen) == 12 and seen[1][0] == seen[0][0] + 2      # windows advance by T - 1
+
+
+def test_offline_sample_taken_by_two_groups(go):
+    """Two unnamed exclusive groups (T = 1): every sample goes to BOTH, the game moves on when both have been
+    stepped (elf/comm_template.h:229-257).  Each group's per-game stream must be the golden stream of the
+    reference module, whatever the order in which the two groups' batches are served."""
+    run = load_golden("batch_streams.json")["runs"][0]
+    cfg = run["cfg"]
+    B = cfg["num_games"]
+    co = go.ContextOptions()
+    co.num_games = B
+    opt = go.GameOptions()
+    opt.seed, opt.mode = cfg["seed"], "offline"
+    opt.list_filename = os.path.join(GOLDEN, "corpus", cfg["lst"])
+    opt.data_aug, opt.start_ratio_pre_moves, opt.ratio_pre_moves = cfg["data_aug"], cfg["start_ratio"], cfg["ratio"]
+    opt.move_cutoff, opt.num_games_per_thread, opt.num_future_actions = cfg["cutoff"], cfg["games_per_thread"], cfg["k"]
+    gc = go.GameContext(co, opt)
+    gids, bufs = [], []
+    for e in range(2):
+        gid = gc.AddCollectors(B, e, 0, gc.CreateGroupStat())
+        gids.append(gid)
+        bufs.append(register(gc, gid, "input", ["s", "offline_a"] + LABELS, e == 0))   # one on the device, one on the host
+    gc.Start()
+    n_check = 60
+    streams = [{g: [] for g in range(B)} for _ in range(2)]
+    served = [0, 0]
+    while min(len(v) for st in streams for v in st.values()) < n_check:
+        infos = gc.Wait(0)
+        k = gids.index(infos.gid)
+        served[k] += 1
+        assert abs(served[0] - served[1]) <= 1                      # a game waits for both takers
+        h = {key: host(v) for key, v in bufs[k].items()}
+        for r in range(len(infos.s)):
+            g = int(h["id"][0, r])
+            streams[k][g].append([int(h[key][0, r]) for key in LABELS] + [[int(a) for a in h["offline_a"][0, r]]] +
+                                 ["%016x" % fnv_planes(FNV_SEED, h["s"][0, r].reshape(-1))])
+        gc.Steps(infos)
+    gc.Stop()
+    for k in range(2):
+        for g in range(B):
+            assert streams[k][g][:n_check] == run["streams"][str(g)][:n_check], (k, g)
