@@ -13,7 +13,7 @@ P2="TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_STALL
 i=0
 for P in "$P1" "$P2"; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d $OUT/gen$i -o g -- python3 $REPO/bench.py --steps 128 --warmup 64 --no-cpu-baseline --no-extra > $OUT/gen$i.json 2> $OUT/gen$i.err
+  timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d $OUT/gen$i -o g -- python3 $REPO/bench.py --steps 2 --warmup 1 --reps 1 --no-cpu-baseline --no-extra > $OUT/gen$i.json 2> $OUT/gen$i.err
   timeout -s KILL 60 rocprofv3 --pmc $P --output-format csv -d $OUT/map$i -o m -- $REPO/tools/store_bench 1024 2 64 2 > $OUT/map$i.txt 2> $OUT/map$i.err
   timeout -s KILL 60 rocprofv3 --pmc $P --output-format csv -d $OUT/split$i -o s -- $REPO/tools/store_bench 1024 2 64 3 > $OUT/split$i.txt 2> $OUT/split$i.err
   timeout -s KILL 60 rocprofv3 --pmc $P --output-format csv -d $OUT/fill$i -o f -- $REPO/tools/store_bench 65536 2 -1 > $OUT/fill$i.txt 2> $OUT/fill$i.err
