@@ -5,8 +5,7 @@
 HBM bytes are corrected as MI355X_MICROARCH.md (HBM / rocprofv3 section) prescribes: FETCH_SIZE and
 WRITE_SIZE are reported in KB; FETCH_SIZE is doubled on gfx950.
 Usage: tools/summarize_pmc.py [--last=N] gpurun_out/<tag> <round> [kernel boards plies per_ply_bytes per_launch_bytes]
-       (--last=N: only the last N launches of the kernel -- for commands whose set-up uses the same kernel;
-        the boards forward with the same kernel and no outputs)
+       (--last=N: only the last N launches of the kernel, for commands whose set-up uses the same kernel)
        e.g. ... gpurun_out/r02a r02                                   (the bench line: k_generate<2>, 1,024 x 64)
             ... gpurun_out/r02g8 r02_generate_8192 "k_generate<3>" 8192 20
             ... gpurun_out/r02p8 r02_ply_8192 "k_ply<3, 1>" 8192 1 36461 3264   (launch per ply)"""
