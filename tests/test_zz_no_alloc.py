@@ -86,3 +86,29 @@ def test_static_entry_point_limits(goenv):
     torch.cuda.synchronize()
     assert int(legal[:n].sum().item()) == n * 361
     assert int(legal[n:].sum().item()) == 0
+
+
+def test_static_entry_point_inside_a_captured_graph(goenv):
+    """What the entry point is for: a caller under HIP graph capture, where hipMalloc is not allowed.  One
+    warm call (set-up), then the call is captured into a graph and the graph replayed on new positions."""
+    dev = torch.device("cuda", 0)
+    n = 257
+    color, lastp, scal = positions(goenv, n, 51, 80)
+    feat = torch.zeros(n, 25, 19, 19, device=dev)
+    legal = torch.zeros(n, 361, dtype=torch.uint8, device=dev)
+    goenv.features_static(color, lastp, scal, feat, legal)            # set-up happens here, outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        goenv.features_static(color, lastp, scal, feat, legal)
+    for seed, plies in ((52, 33), (53, 150)):
+        c2, l2, s2 = positions(goenv, n, seed, plies)
+        color.copy_(c2)
+        lastp.view(torch.int16).copy_(l2.view(torch.int16))
+        scal.copy_(s2)
+        feat.fill_(-1.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        want_f, want_l = via_context(goenv, c2, l2, s2, None)
+        assert torch.equal(feat.view(torch.int32), want_f.view(torch.int32))
+        assert torch.equal(legal, want_l)
