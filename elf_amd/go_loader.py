@@ -112,7 +112,12 @@ def initialize(args):
     opt.end_on_two_passes = args.end_on_two_passes
     opt.signal_restart = args.signal_restart
     opt.board_id_base = args.board_id_base
+    if getattr(args, "verbose", False):               # the reference prints these unconditionally (go/game.py:46,59-62)
+        co.print()
     GC = go.GameContext(co, opt)
     params = GC.GetParams()
+    if getattr(args, "verbose", False):
+        print("Version: ", GC.Version())
+        print("Num Actions: ", params["num_action"])
     params.update(dict(num_group=1 if args.actor_only else 2, T=args.T))
     return GCWrapper(GC, co, descriptors(args), gpu=args.gpu, use_numpy=False, params=params)
