@@ -378,7 +378,7 @@ def game_context_selfplay(B, seed, fuse, steps=1500, warm=100):
     stats = gc.Stats()
     gc.Stop()
     return {"moves_per_s": B * steps / dt, "step_ms": dt * 1e3 / steps, "host_us_per_batch": host * 1e6 / steps,
-            "launches_per_step": (1 if B <= 4096 else 2) if fuse else 3, "steps": steps, "games_finished": stats[0],
+            "launches_per_step": (1 if B <= 3072 else 2) if fuse else 3, "steps": steps, "games_finished": stats[0],
             "GBps": B * ALG_BYTES_PER_BOARD / (dt / steps) / 1e9}
 
 

@@ -931,10 +931,13 @@ static int pick_nw_features(const goenv_ctx* c, int count) {
 // How the planes are stored: bit 0 = the 11 constant planes first (tuning knob, no gain
 // measured), bit 1 = write-through (`sc1`) plane stores.  Write-through pays for launches whose
 // whole output fits the caches (no end-of-kernel write-back of tens of MB: 13.2 -> 12.1 us at
-// 1,024 boards) and costs 1.5x on an HBM-sized stream, so it is used for small launches only.
+// 1,024 boards) and costs 1.5x on an HBM-sized stream, so it is used for launches of up to 4,096 boards.
 static int pick_zero_first(const goenv_ctx* c, int count) {
   if (c->zero_first >= 0) return c->zero_first;
-  return count <= 1536 ? 2 : 0;
+  // tools/tune_waves.py under GOENV_ZERO_FIRST=0 / 2: write-through wins up to 6,144 boards (16.5 -> 14.6 us at
+  // 1,536, 18.8 -> 17.0 at 2,048, 31.5 -> 30.5 at 4,096, 42.9 -> 42.4 at 6,144) and loses badly once a ply's planes
+  // no longer fit the 256-MB Infinity Cache (8,192 boards = 296 MB: 57 -> 89 us)
+  return count <= 4096 ? 2 : 0;
 }
 
 // Waves per board of a launch over `count` boards.  Small launches are bound by the dependent
@@ -1016,11 +1019,11 @@ int goenv_create(int device, int n_boards, uint64_t seed, int64_t board_id_base,
   if (const char* e = getenv("GOENV_ZERO_FIRST")) c->zero_first = atoi(e) & 3;
   c->xcd_map = 1;
   if (const char* e = getenv("GOENV_XCD_MAP")) c->xcd_map = atoi(e) ? 1 : 0;
-  // measured (tools/time_api_sweep.py, profiles/r02_api_sweep.txt): up to 4,096 boards one launch wins
-  // (13.1 against 15.7 us at 1,024); beyond, the policy row is one more read in front of every
-  // workgroup's chain while the chip is saturated with plane stores, and the sampler as a small launch
-  // of its own is faster (8,192 boards: 59.7 against 78.2 us)
-  c->fuse_max = 4096;
+  // measured (tools/time_api_sweep.py, profiles/r02_api_sweep.txt): up to 3,072 boards one launch wins
+  // (13.1 against 15.3 us at 1,024, 18.1 against 20.3 at 2,048, 28.4 against 28.3 at 3,072); beyond, the policy
+  // row is one more read in front of every workgroup's chain while the chip is saturated with plane stores, and
+  // the sampler as a small launch of its own is faster (4,096: 34.2 against 35.0 us; 8,192: 59.7 against 78.2)
+  c->fuse_max = 3072;
   if (const char* e = getenv("GOENV_FUSE_MAX")) c->fuse_max = atoi(e);
   if (const char* e = getenv("GOENV_WAVES_PER_BOARD")) {
     const int v = atoi(e);
@@ -1370,7 +1373,7 @@ int goenv_features_static(int device, int n, const uint8_t* color, const uint16_
   goenv_sample_out none;
   memset(&none, 0, sizeof(none));
   GO_LAUNCH(nw, k_features, n, S(stream), recs, n, (const int32_t*)nullptr, 0, n, aug_codes, lut, feat_out, legal_out,
-            none, 0, d->lut1, n <= 1536 ? 2 : 0, 1);
+            none, 0, d->lut1, 2, 1);   // write-through plane stores: n <= 4,096 fits the Infinity Cache
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -275,7 +275,7 @@ int goenv_ply_sel(goenv_ctx* ctx, const int32_t* idx, int first, int count, uint
  * not RANDOM_POLICY or AUTO_RESTART: the move is sampled for the position as stored),
  * and the NEXT sample's planes (frame aug_codes), legal mask and sequencing record are written
  * straight into the batch arrays.  actions_out int32 [count] receives the sampled move.  One
- * launch up to 4,096 boards; above, the sampler runs as a small launch of its own in front of
+ * launch up to 3,072 boards; above, the sampler runs as a small launch of its own in front of
  * the ply kernel (measured faster there; same moves and outputs; its int64 [n_boards] move buffer
  * is allocated by the first such call). */
 int goenv_ply_policy_sel(goenv_ctx* ctx, const int32_t* idx, int first, int count, uint32_t flags,

@@ -1,6 +1,6 @@
 """GPU soak: EVERY float of every board's planes and every legal-mask byte, on every ply, for the
-launch shapes the benchmark uses (1,024 boards: three waves per board + write-through stores;
-2,048 boards: plain stores), against oracle boards replaying the same moves.  ~250,000 board-plies:
+launch shapes the benchmark uses (1,024 and 2,048 boards: three waves per board + write-through stores;
+4,200 boards: plain stores), against oracle boards replaying the same moves.  ~250,000 board-plies:
 a fault that corrupts one float in a thousand board-plies (an unguarded store-data hazard behind the
 inline-asm write-through store did exactly that) cannot hide here."""
 import numpy as np
@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-@pytest.mark.parametrize("boards,plies,parts", [(1024, 120, 1), (2048, 40, 1), (1024, 60, 2)])
+@pytest.mark.parametrize("boards,plies,parts", [(1024, 120, 1), (2048, 40, 1), (1024, 60, 2), (4200, 10, 1)])
 def test_all_planes_of_all_boards_every_ply(boards, plies, parts):
     from elf_amd import goenv
     goenv.load_library()
