@@ -249,6 +249,25 @@ class RefBoard(_Board):
                     winner=w.value, handi=h.value, board_size=bs.value)
 
 
+DIFF_SO = os.path.join(HERE, "_ref", "libgodiff.so")
+DIFF_COUNTS = ("plies", "games", "applied", "illegal", "passes", "resigns", "ko_set", "captures", "extracts",
+               "scores", "tactics", "handicap_games", "dropped_maxgroup", "game_ends", "checkmove_sweeps",
+               "max_groups")
+
+
+def diff_fuzz(seed, target_plies, threads):
+    """Native reference-vs-restatement loop (oracle/diff_fuzz.cc).  Returns (error or None, counts)."""
+    lib = C.CDLL(DIFF_SO)
+    n = lib.godiff_num_counts()
+    assert n == len(DIFF_COUNTS)
+    lib.godiff_run.restype = C.c_int
+    lib.godiff_run.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.c_char_p, C.c_int]
+    cnt = (C.c_int64 * n)()
+    err = C.create_string_buffer(512)
+    rc = lib.godiff_run(seed, target_plies, threads, cnt, err, 512)
+    return (err.value.decode() if rc else None), dict(zip(DIFF_COUNTS, list(cnt)))
+
+
 def fnv_planes(h, planes):
     """64-bit FNV-1a-style hash over the float bit patterns:
     h = (h ^ u32) * 0x100000001b3, seed 0xcbf29ce484222325."""

@@ -42,6 +42,28 @@ def test_random_games_with_passes_illegal_probes_and_handicap(seed):
                 break
 
 
+def test_native_differential_fuzz_two_million_plies(capsys):
+    """oracle/diff_fuzz.cc: reference board.cc / board_feature.cc against the restatement inside one C
+    loop ("millions of random plies").  Every ply: forward() result, game-end flag, canonical
+    view, legal and candidate masks; on shares of the plies all 9,025 plane floats under a random D4 code,
+    Tromp-Taylor and both fast scores, TryPlay2 of every point, the heuristic filters, the policy move."""
+    import os
+    from oracle import pyoracle
+    if not os.path.exists(pyoracle.DIFF_SO):
+        pytest.skip("oracle/_ref/libgodiff.so not built")
+    target = int(os.environ.get("GOENV_FUZZ_PLIES", "2000000"))
+    err, n = pyoracle.diff_fuzz(20261111, target, min(8, os.cpu_count() or 1))
+    with capsys.disabled():
+        print("\n[diff_fuzz] " + " ".join("%s=%d" % kv for kv in n.items()))
+    assert err is None, err
+    assert n["plies"] >= target
+    # the fuzz reaches what it is meant to reach
+    assert n["illegal"] > target // 100 and n["passes"] > target // 200 and n["ko_set"] > target // 1000
+    assert n["captures"] > target // 50 and n["extracts"] > target // 8 and n["scores"] > target // 16
+    assert n["handicap_games"] > 100 and n["game_ends"] > 100 and n["resigns"] > 10 and n["tactics"] > 1000
+    assert n["max_groups"] < 165
+
+
 def test_policy_and_d4_agree():
     for bid in range(4):
         r, o = RefBoard(), OracleBoard()
