@@ -249,6 +249,84 @@ class RefBoard(_Board):
                     winner=w.value, handi=h.value, board_size=bs.value)
 
 
+class RefBatch:
+    """n reference boards (the unmodified board.cc `Board`) in one array, stepped and compared natively
+    (goref_batch_check, oracle/ref_harness.cc) so that a GPU test can replay EVERY board of a launch
+    through the reference on every ply.  `board(b)` is a RefBoard view of one of them."""
+    WHAT = ("", "legality", "colours", "liberties", "group sizes", "last_placed", "scalars", "legal mask", "planes")
+
+    def __init__(self, n, threads=None):
+        api = RefBoard.api()
+        lib = RefBoard._lib
+        self.lib = lib
+        self.n = n
+        self.threads = threads or min(16, os.cpu_count() or 1)
+        self.stride = (api["sizeof_board"]() + 63) // 64 * 64
+        self._buf = C.create_string_buffer(self.stride * n + 64)
+        self.base = (C.addressof(self._buf) + 63) // 64 * 64
+        for b in range(n):
+            api["clear"](C.c_void_p(self.base + b * self.stride))
+        P = C.c_void_p
+        lib.goref_batch_check.restype = C.c_int
+        lib.goref_batch_check.argtypes = [P, C.c_int, C.c_int] + [P] * 10 + [C.c_int, P]
+        lib.goref_batch_policy.restype = None
+        lib.goref_batch_policy.argtypes = [P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, P, P, C.c_int]
+        lib.goref_batch_ended.restype = C.c_int
+        lib.goref_batch_ended.argtypes = [P, C.c_int, C.c_int, C.c_int, P]
+
+    def board(self, b):
+        o = RefBoard.__new__(RefBoard)
+        o._buf = self._buf                     # keeps the array alive
+        o.ptr = C.c_void_p(self.base + b * self.stride)
+        return o
+
+    @staticmethod
+    def _p(a, dtype):
+        if a is None:
+            return None, None
+        a = np.ascontiguousarray(a, dtype)
+        return a, a.ctypes.data_as(C.c_void_p)
+
+    def check(self, actions=None, want_legal=None, state=None, legal=None, planes=None, aug=None, where=""):
+        """Play actions (int32 [n], -3 = none) on the reference boards, then compare whatever is given:
+        state = dict of the canonical arrays as goenv.get_state() returns them (numpy), legal u8 [n, 361],
+        planes f32 [n, 9025] under aug int32 [n].  Raises AssertionError naming the first difference."""
+        keep = []
+
+        def p(a, dtype, rows=None):
+            a, ptr = self._p(a, dtype)
+            if a is not None:
+                assert a.shape[0] == self.n, "batch array of %d rows for %d boards" % (a.shape[0], self.n)
+                keep.append(a)
+            return ptr
+        st = state or {}
+        sc = st.get("scalars")
+        if sc is not None:
+            assert np.asarray(sc).shape == (self.n, 16)
+        bad3 = np.zeros(3, np.int32)
+        nbad = self.lib.goref_batch_check(
+            C.c_void_p(self.base), self.stride, self.n, p(actions, np.int32), p(want_legal, np.int32),
+            p(st.get("color"), np.uint8), p(st.get("liberties"), np.int16), p(st.get("stones"), np.int16),
+            p(st.get("last_placed"), np.uint16), p(sc, np.int32), p(legal, np.uint8),
+            p(None if planes is None else np.asarray(planes).reshape(self.n, -1), np.float32), p(aug, np.int32),
+            self.threads, bad3.ctypes.data_as(C.c_void_p))
+        if nbad:
+            raise AssertionError("%s: %d of %d boards differ from the reference; first: board %d, %s, index %d" % (
+                where, nbad, self.n, bad3[0], self.WHAT[bad3[1]], bad3[2]))
+
+    def policy(self, seed, games=None, id_base=0):
+        out = np.zeros(self.n, np.int32)
+        g, gp = self._p(games, np.int32)
+        self.lib.goref_batch_policy(C.c_void_p(self.base), self.stride, self.n, seed, id_base, gp,
+                                    out.ctypes.data_as(C.c_void_p), self.threads)
+        return out
+
+    def ended(self, max_ply):
+        out = np.zeros(self.n, np.uint8)
+        self.lib.goref_batch_ended(C.c_void_p(self.base), self.stride, self.n, max_ply, out.ctypes.data_as(C.c_void_p))
+        return out
+
+
 DIFF_SO = os.path.join(HERE, "_ref", "libgodiff.so")
 DIFF_COUNTS = ("plies", "games", "applied", "illegal", "passes", "resigns", "ko_set", "captures", "extracts",
                "scores", "tactics", "handicap_games", "dropped_maxgroup", "game_ends", "checkmove_sweeps",

@@ -291,4 +291,117 @@ int64_t goref_bench_playouts(int n_boards, int threads, uint64_t seed, int max_p
   return total_plies.load();
 }
 
+// Batch checker for the GPU-vs-reference tests (tests/test_gpu_vs_reference.py): `n` reference boards in
+// one array (`stride` bytes apart).  For board b: if actions[b] != -3 play it through TryPlay2 + Play
+// (GoState::forward) and require legality == want_legal[b] (or legal when want_legal is NULL); then compare the
+// reference's canonical view, FindAllValidMoves mask and all 25 planes under aug[b] with the arrays
+// the GPU produced (any of them may be NULL).  Returns the number of boards with a difference;
+// first_bad[0] = lowest such board, first_bad[1] = what differed (1 legality, 2 colours, 3 liberties,
+// 4 group sizes, 5 last_placed, 6 scalars, 7 legal mask, 8 planes), first_bad[2] = index in that array.
+int goref_batch_check(void* boards, int stride, int n, const int32_t* actions, const int32_t* want_legal,
+                      const uint8_t* color, const int16_t* libs, const int16_t* stones,
+                      const uint16_t* lastp, const int32_t* sc, const uint8_t* legal, const float* planes,
+                      const int32_t* aug, int threads, int32_t* first_bad) {
+  if (threads < 1) threads = 1;
+  std::atomic<int> next(0), bad(0);
+  std::atomic<int> lowest(n);
+  std::vector<int32_t> why(n, 0), where(n, 0);
+  auto worker = [&]() {
+    std::vector<float> f;
+    uint8_t c[NUM_INTERSECTION], m[NUM_INTERSECTION];
+    int16_t l[NUM_INTERSECTION], st[NUM_INTERSECTION];
+    uint16_t lp[NUM_INTERSECTION];
+    int32_t s[16];
+    for (;;) {
+      int b = next.fetch_add(1);
+      if (b >= n) break;
+      Board* board = (Board*)((char*)boards + (size_t)b * stride);
+      int w = 0, at = 0;
+      if (actions && actions[b] != -3) {
+        GroupId4 ids;
+        bool ok = TryPlay2(board, action_to_coord(actions[b]), &ids);
+        if (ok) Play(board, &ids);
+        if ((int)ok != (want_legal ? want_legal[b] : 1)) w = 1;
+      }
+      if (!w) {
+        goref_canonical(board, c, l, st, lp, s);
+        auto diff = [&](const void* a, const void* g, size_t elem, size_t count) -> int {
+          if (!g || !memcmp(a, g, elem * count)) return -1;
+          for (size_t i = 0; i < count; ++i)
+            if (memcmp((const char*)a + i * elem, (const char*)g + i * elem, elem)) return (int)i;
+          return 0;
+        };
+        int d;
+        if ((d = diff(c, color ? color + (size_t)b * NUM_INTERSECTION : 0, 1, NUM_INTERSECTION)) >= 0) { w = 2; at = d; }
+        else if ((d = diff(l, libs ? libs + (size_t)b * NUM_INTERSECTION : 0, 2, NUM_INTERSECTION)) >= 0) { w = 3; at = d; }
+        else if ((d = diff(st, stones ? stones + (size_t)b * NUM_INTERSECTION : 0, 2, NUM_INTERSECTION)) >= 0) { w = 4; at = d; }
+        else if ((d = diff(lp, lastp ? lastp + (size_t)b * NUM_INTERSECTION : 0, 2, NUM_INTERSECTION)) >= 0) { w = 5; at = d; }
+        else if ((d = diff(s, sc ? sc + (size_t)b * 16 : 0, 4, 11)) >= 0) { w = 6; at = d; }
+      }
+      if (!w && legal) {
+        goref_legal(board, m);
+        for (int p = 0; p < NUM_INTERSECTION && !w; ++p)
+          if (m[p] != legal[(size_t)b * NUM_INTERSECTION + p]) { w = 7; at = p; }
+      }
+      if (!w && planes) {
+        int code = aug ? aug[b] : 0;
+        BoardFeature bf(*board, (BoardFeature::Rot)(code % 4), (code >> 2) == 1);
+        bf.Extract(&f);
+        const float* g = planes + (size_t)b * MAX_NUM_FEATURE * NUM_INTERSECTION;
+        if (memcmp(f.data(), g, sizeof(float) * MAX_NUM_FEATURE * NUM_INTERSECTION)) {
+          w = 8;
+          for (int i = 0; i < MAX_NUM_FEATURE * NUM_INTERSECTION; ++i)
+            if (memcmp(&f[i], &g[i], 4)) { at = i; break; }
+        }
+      }
+      if (w) {
+        why[b] = w; where[b] = at;
+        bad.fetch_add(1);
+        int cur = lowest.load();
+        while (b < cur && !lowest.compare_exchange_weak(cur, b)) {}
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+  for (auto& th : pool) th.join();
+  if (first_bad) {
+    int b = lowest.load();
+    first_bad[0] = b < n ? b : -1;
+    first_bad[1] = b < n ? why[b] : 0;
+    first_bad[2] = b < n ? where[b] : 0;
+  }
+  return bad.load();
+}
+
+// Batch helpers of the same tests.  goref_batch_policy: the cfg-2 policy move of every board
+// (game counter per board).  goref_batch_ended: 1 where IsGameEnd or _ply > max_ply (what the device
+// restarts before the next ply under AUTO_RESTART).
+void goref_batch_policy(const void* boards, int stride, int n, uint64_t seed, uint64_t id_base,
+                        const int32_t* games, int32_t* out, int threads) {
+  if (threads < 1) threads = 1;
+  std::atomic<int> next(0);
+  auto worker = [&]() {
+    for (;;) {
+      int b = next.fetch_add(1);
+      if (b >= n) break;
+      out[b] = goref_policy_move((const char*)boards + (size_t)b * stride, seed, id_base + (uint64_t)b,
+                                 games ? (uint64_t)games[b] : 0);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+  for (auto& th : pool) th.join();
+}
+
+int goref_batch_ended(const void* boards, int stride, int n, int max_ply, uint8_t* out) {
+  int k = 0;
+  for (int b = 0; b < n; ++b) {
+    const Board* board = (const Board*)((const char*)boards + (size_t)b * stride);
+    out[b] = (IsGameEnd(board) || (max_ply > 0 && board->_ply > max_ply)) ? 1 : 0;
+    k += out[b];
+  }
+  return k;
+}
+
 }  // extern "C"
