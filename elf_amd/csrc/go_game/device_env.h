@@ -49,8 +49,10 @@ class DevBuf {
 // The boards of one GameContext on one GPU.
 class DeviceEnv {
  public:
-  DeviceEnv(int device, int n_boards, uint64_t seed, int64_t id_base, float komi, int max_ply) : n_(n_boards) {
-    chk(goenv_create(device, n_boards, seed, id_base, komi, max_ply, &ctx_), "goenv_create");
+  // `scratch` = 1 adds one board behind the context's own (index n()) for count_legal_prefix
+  DeviceEnv(int device, int n_boards, uint64_t seed, int64_t id_base, float komi, int max_ply, int scratch = 0)
+      : n_(n_boards), scratch_(scratch ? n_boards : -1) {
+    chk(goenv_create(device, n_boards + (scratch ? 1 : 0), seed, id_base, komi, max_ply, &ctx_), "goenv_create");
   }
   DeviceEnv(const DeviceEnv&) = delete;
   DeviceEnv& operator=(const DeviceEnv&) = delete;
@@ -107,9 +109,19 @@ class DeviceEnv {
     return applied;
   }
 
+  // How many of `moves` GoState::forward accepts when they are replayed from an empty board with
+  // `handicap` stones: one reset + one replay launch on the scratch board, synchronous.  Run once per
+  // SGF record, when a loader first uses it.
+  int count_legal_prefix(int handicap, const std::vector<int16_t>& moves) {
+    if (scratch_ < 0) throw std::runtime_error("count_legal_prefix: the context has no scratch board");
+    reset_one(scratch_, handicap);
+    return replay_one(scratch_, moves.data(), (int)moves.size());
+  }
+
  private:
   goenv_ctx* ctx_ = nullptr;
   int n_ = 0;
+  int scratch_ = -1;
   void* stream_ = nullptr;
   DevBuf one_i32_, one_i32b_, one_i64_, moves_;
 };

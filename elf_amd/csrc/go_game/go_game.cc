@@ -338,7 +338,7 @@ class GameContext {
     const long long n_boards = (long long)co_.num_games * (mcts_ ? 1 + pool : npt);
     if (n_boards > (1ll << 30)) throw std::range_error("Start(): num_games x node pool exceeds 2^30 boards");
     env_.reset(new DeviceEnv(opt_.gpu, (int)n_boards, opt_.seed ? opt_.seed : 1, opt_.board_id_base, opt_.komi,
-                             opt_.ply_cap));
+                             opt_.ply_cap, offline_ ? 1 : 0));
     env_->set_stream(stream_);
     games_.clear();
     games_.resize(co_.num_games);
@@ -379,6 +379,7 @@ class GameContext {
         produce_sample(g);
       }
     }
+    if (offline_) offline_flush_all();   // the first load's pre-moves of every replay, a few large launches
     started_ = true;
     if (general_) {
       std::vector<int> all(co_.num_games);
@@ -483,6 +484,10 @@ class GameContext {
     if (game_idx < 0 || game_idx >= co_.num_games) return "Invalid game_idx [" + std::to_string(game_idx) + "]";
     need_env();
     const int board = offline_ ? games_[game_idx].loaders[games_[game_idx].sample.loader]->board() : game_idx;
+    if (offline_) {   // what the replay's board still owes (the last next()), so that the print is the host's position
+      std::vector<OfflineLoader*> one{games_[game_idx].loaders[games_[game_idx].sample.loader].get()};
+      offline_launch(one, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    }
     DevBuf col, sc;
     col.ensure(env_->ctx(), GOENV_NUM_POINTS);
     sc.ensure(env_->ctx(), 64);
@@ -813,17 +818,12 @@ class GameContext {
     for (int r = 1; r < n; ++r)
       if (c.boards[r] != c.boards[0] + r) { c.contiguous = false; break; }
     const int32_t* d_idx = nullptr;
-    if (!c.contiguous) {
+    if (!c.contiguous && !offline_) {
       c.idx.ensure(env_->ctx(), (size_t)n * 4);
       env_->h2d(c.idx.get(), c.boards.data(), (size_t)n * 4);
       d_idx = c.idx.as<int32_t>();
     }
     const int32_t* d_aug = nullptr;
-    if (offline_) {
-      c.aug.ensure(env_->ctx(), (size_t)n * 4);
-      env_->h2d(c.aug.get(), aug.data(), (size_t)n * 4);
-      d_aug = c.aug.as<int32_t>();
-    }
     bool st_s = false, st_l = false, st_m[8] = {false, false, false, false, false, false, false, false};
     float* d_s = out_ptr<float>(c, "s", c.stage_s, (size_t)n * GOENV_FEAT_FLOATS * 4, &st_s);
     uint8_t* d_l = out_ptr<uint8_t>(c, "legal", c.stage_legal, (size_t)n * GOENV_NUM_POINTS, &st_l);
@@ -843,8 +843,29 @@ class GameContext {
     // the device always advances seq in selfplay mode, registered or not
     const goenv_sample_out* meta_arg = host_meta ? nullptr : &so;
     (void)want_dev_meta;
-    chk(goenv_collect_sel(env_->ctx(), d_idx, c.contiguous ? c.boards[0] : 0, n, d_aug, d_s, d_l, meta_arg,
-                          env_->stream()), "goenv_collect_sel");
+    if (offline_) {
+      // ONE launch for the whole batch: what every replay's board owes (the move of its last next(), or a
+      // reload's reset + handicap + pre-moves), the planes under the sample's D4 code, and the labels the
+      // host computed above, straight into the registered device tensors (go/offpolicy_loader.cc:120-145)
+      std::vector<OfflineLoader*> lds(n);
+      for (int r = 0; r < n; ++r) lds[r] = games_[c.games[r]].loaders[games_[c.games[r]].sample.loader].get();
+      goenv_sample_out lab;
+      std::memset(&lab, 0, sizeof(lab));
+      void** fields[8] = {(void**)&lab.id, (void**)&lab.seq, (void**)&lab.game_counter, (void**)&lab.last_terminal,
+                          (void**)&lab.move_idx, (void**)&lab.winner, (void**)&lab.aug_code, (void**)&lab.game_record_idx};
+      for (int k = 0; k < 8; ++k) {
+        auto it = c.input.find(kMetaKeys[k]);
+        if (it != c.input.end() && it->second.device) *fields[k] = it->second.p;
+      }
+      auto ita = c.input.find("offline_a");
+      int64_t* d_offa = (ita != c.input.end() && ita->second.device) ? (int64_t*)ita->second.p : nullptr;
+      const int32_t* mp[8];
+      for (int k = 0; k < 8; ++k) mp[k] = meta[k].data();
+      offline_launch(lds, aug.data(), mp, off_a.data(), d_s, d_l, &lab, d_offa);
+    } else {
+      chk(goenv_collect_sel(env_->ctx(), d_idx, c.contiguous ? c.boards[0] : 0, n, d_aug, d_s, d_l, meta_arg,
+                            env_->stream()), "goenv_collect_sel");
+    }
     bool need_sync = false;
     auto flush = [&](const std::string& key, DevBuf& stage, bool staged, size_t bytes) {
       if (!staged) return;
@@ -858,6 +879,7 @@ class GameContext {
       for (int k = 0; k < 8; ++k) {
         auto it = c.input.find(kMetaKeys[k]);
         if (it == c.input.end()) continue;
+        if (offline_ && it->second.device) continue;   // written by the batch's launch
         if (k == 3) {
           std::vector<int8_t> lt(n);
           for (int r = 0; r < n; ++r) lt[r] = (int8_t)meta[3][r];
@@ -867,7 +889,7 @@ class GameContext {
         }
       }
       auto it = c.input.find("offline_a");
-      if (it != c.input.end() && offline_) put(it->second, off_a.data(), off_a.size() * 8);
+      if (it != c.input.end() && offline_ && !it->second.device) put(it->second, off_a.data(), off_a.size() * 8);
     }
     // host-resident tensors must be complete when Wait returns; device tensors are stream-ordered
     if (need_sync) env_->sync();
@@ -1125,9 +1147,16 @@ class GameContext {
         env_->h2d(g_act_.get(), augs.data(), (size_t)m * 4);
         if (want_s) g_stage_s_.ensure(env_->ctx(), (size_t)m * GOENV_FEAT_FLOATS * 4);
         if (want_l) g_stage_l_.ensure(env_->ctx(), (size_t)m * GOENV_NUM_POINTS);
-        chk(goenv_collect_sel(env_->ctx(), g_idx_.as<int32_t>(), 0, m, g_act_.as<int32_t>(),
-                              want_s ? g_stage_s_.as<float>() : nullptr, want_l ? g_stage_l_.as<uint8_t>() : nullptr, nullptr,
-                              env_->stream()), "goenv_collect_sel");
+        if (offline_) {   // what the boards owe + the planes, one launch (labels stay with the host's histories)
+          std::vector<OfflineLoader*> lds(m);
+          for (int i = 0; i < m; ++i) lds[i] = games_[games[i]].loaders[games_[games[i]].sample.loader].get();
+          offline_launch(lds, augs.data(), nullptr, nullptr, want_s ? g_stage_s_.as<float>() : nullptr,
+                         want_l ? g_stage_l_.as<uint8_t>() : nullptr, nullptr, nullptr);
+        } else {
+          chk(goenv_collect_sel(env_->ctx(), g_idx_.as<int32_t>(), 0, m, g_act_.as<int32_t>(),
+                                want_s ? g_stage_s_.as<float>() : nullptr, want_l ? g_stage_l_.as<uint8_t>() : nullptr, nullptr,
+                                env_->stream()), "goenv_collect_sel");
+        }
         if (want_s)
           chk(goenv_copy_rows(env_->ctx(), g_stage_s_.get(), nullptr, ring_["s"].get(), g_rows_.as<int32_t>(), m,
                               (size_t)GOENV_FEAT_FLOATS * 4, env_->stream()), "goenv_copy_rows");
@@ -1170,30 +1199,11 @@ class GameContext {
   // handle_response + forward for games whose every taker is done (or that had none)
   void act_general(const std::vector<int>& games) {
     const int m = (int)games.size();
-    if (offline_) {   // OfflineLoader::handle_response -> next(), batched as in steps_offline
-      std::vector<int32_t> boards;
-      std::vector<int64_t> acts;
-      std::vector<OfflineLoader*> who;
+    if (offline_) {   // OfflineLoader::handle_response -> next(): host bookkeeping (see steps_offline)
       for (int g : games) {
         GameSlot& gs = games_[g];
-        OfflineLoader* ld = gs.loaders[gs.sample.loader].get();
-        const int a = ld->begin_next();
-        if (a == -100) continue;
-        boards.push_back(ld->board());
-        acts.push_back(a);
-        who.push_back(ld);
+        gs.loaders[gs.sample.loader]->next();
       }
-      const int n = (int)boards.size();
-      if (n == 0) return;
-      g_idx_.ensure(env_->ctx(), (size_t)n * 4); g_act_.ensure(env_->ctx(), (size_t)n * 8); g_status_.ensure(env_->ctx(), (size_t)n * 4);
-      env_->h2d(g_idx_.get(), boards.data(), (size_t)n * 4);
-      env_->h2d(g_act_.get(), acts.data(), (size_t)n * 8);
-      chk(goenv_ply_sel(env_->ctx(), g_idx_.as<int32_t>(), 0, n, 0u, g_act_.as<int64_t>(), nullptr, nullptr, nullptr, nullptr,
-                        nullptr, g_status_.as<int32_t>(), env_->stream()), "goenv_ply_sel");
-      std::vector<int32_t> st(n);
-      env_->d2h(st.data(), g_status_.get(), (size_t)n * 4);
-      env_->sync();
-      for (int i = 0; i < n; ++i) who[i]->end_next(st[i] == 1);
       return;
     }
     // play modes: the move is the newest history entry's reply -- `a` if a collector replies it, else
@@ -1361,32 +1371,67 @@ class GameContext {
   // offline: OfflineLoader::handle_response -> next() for every sample of the batch
   // (go/offpolicy_loader.cc:147-152,120-126); the common case is one batched forward
   void steps_offline(Collector& c) {
-    const int n = (int)c.games.size();
-    std::vector<int32_t> boards;
-    std::vector<int64_t> acts;
-    std::vector<OfflineLoader*> who;
-    for (int r = 0; r < n; ++r) {
-      GameSlot& gs = games_[c.games[r]];
-      OfflineLoader* ld = gs.loaders[gs.sample.loader].get();
-      const int a = ld->begin_next();
-      if (a == -100) continue;
-      boards.push_back(ld->board());
-      acts.push_back(a);
-      who.push_back(ld);
+    for (int ticket : c.games) {
+      GameSlot& gs = games_[ticket];
+      gs.loaders[gs.sample.loader]->next();   // host bookkeeping; the board is brought up to date when it is next sampled
     }
-    const int m = (int)boards.size();
-    if (m == 0) return;
-    c.idx.ensure(env_->ctx(), (size_t)m * 4);
-    c.actions.ensure(env_->ctx(), (size_t)m * 8);
-    c.status.ensure(env_->ctx(), (size_t)m * 4);
-    env_->h2d(c.idx.get(), boards.data(), (size_t)m * 4);
-    env_->h2d(c.actions.get(), acts.data(), (size_t)m * 8);
-    chk(goenv_ply_sel(env_->ctx(), c.idx.as<int32_t>(), 0, m, 0u, c.actions.as<int64_t>(), nullptr, nullptr, nullptr,
-                      nullptr, nullptr, c.status.as<int32_t>(), env_->stream()), "goenv_ply_sel");
-    std::vector<int32_t> st(m);
-    env_->d2h(st.data(), c.status.get(), (size_t)m * 4);
-    env_->sync();
-    for (int i = 0; i < m; ++i) who[i]->end_next(st[i] == 1);
+  }
+
+  // Packs what the replays' boards owe (+ the sample each is about to give, if any) into a block of the
+  // library's pinned staging ring and issues the one launch that does it all (goenv_offline_batch).
+  // aug / meta / off_a describe the samples (NULL: no sample, boards only); d_s / d_l / lab / d_offa are the
+  // device destinations (any may be NULL).
+  void offline_launch(const std::vector<OfflineLoader*>& lds, const int32_t* aug, const int32_t* const* meta,
+                      const int64_t* off_a, float* d_s, uint8_t* d_l, const goenv_sample_out* lab, int64_t* d_offa) {
+    const int n = (int)lds.size();
+    if (n == 0) return;
+    const int k = std::min(opt_.num_future_actions, GOENV_MAX_FUTURE);
+    const int row_w = 12 + 2 * k;
+    size_t total_moves = 0;
+    for (OfflineLoader* ld : lds) total_moves += (size_t)ld->pending().count;
+    const size_t moves_off = (size_t)n * row_w * 4;
+    void* block = nullptr;
+    chk(goenv_stage_acquire(env_->ctx(), moves_off + total_moves * 2 + 16, &block), "goenv_stage_acquire");
+    int32_t* rows = static_cast<int32_t*>(block);
+    int16_t* mv = reinterpret_cast<int16_t*>(static_cast<char*>(block) + moves_off);
+    size_t at = 0;
+    for (int r = 0; r < n; ++r) {
+      OfflineLoader& ld = *lds[r];
+      const PendingOp& op = ld.pending();
+      int32_t* row = rows + (size_t)r * row_w;
+      row[0] = ld.board();
+      row[1] = (int32_t)((uint32_t)(aug ? aug[r] & 7 : 0) | (op.reset ? 8u : 0u) | ((uint32_t)(op.handi & 15) << 4) |
+                         ((uint32_t)op.count << 8));
+      row[2] = (int32_t)at;
+      row[3] = 0;
+      for (int f = 0; f < 8; ++f) row[4 + f] = meta ? meta[f][r] : 0;
+      if (off_a && k > 0) std::memcpy(row + 12, off_a + (size_t)r * opt_.num_future_actions, (size_t)k * 8);
+      else std::memset(row + 12, 0, (size_t)k * 8);
+      if (op.count > 0) {
+        std::memcpy(mv + at, op.rec->moves.data() + op.from, (size_t)op.count * 2);
+        at += (size_t)op.count;
+      }
+      ld.clear_pending();
+    }
+    chk(goenv_offline_batch(env_->ctx(), block, n, k, moves_off, d_s, d_l, lab, d_offa, env_->stream()),
+        "goenv_offline_batch");
+  }
+
+  // every replay whose board owes something, in launches of at most 16,384 rows (Start(): the first
+  // load of each replay fast-forwards up to half a record)
+  void offline_flush_all() {
+    std::vector<OfflineLoader*> lds;
+    auto go = [&]() {
+      offline_launch(lds, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+      lds.clear();
+    };
+    for (GameSlot& gs : games_)
+      for (auto& ld : gs.loaders)
+        if (!ld->pending().empty()) {
+          lds.push_back(ld.get());
+          if (lds.size() == 16384) go();
+        }
+    go();
   }
 };
 

@@ -4,11 +4,18 @@
 // What stays on the host: the SGF records, the position of each replay inside its record, the
 // std::mt19937 streams (same engine, same seeds, same call order as the reference, so that a
 // fixed GameOptions.seed gives the reference's samples) and the per-game sequencing.
-// What runs on the device: every rules operation -- Reset/ApplyHandicap (goenv_reset), the
-// pre-move fast-forward of after_reload (goenv_replay, one launch per reload), the per-sample
-// forward() (batched by the GameContext into one goenv_ply_sel launch) and Extract.
+// What runs on the device: every rules operation -- Reset/ApplyHandicap, the pre-move fast-forward of
+// after_reload, the per-sample forward() and Extract.
+//
+// The host never waits for the device.  A replay's board is always "its record, replayed from the
+// start, up to move idx", and whether forward() accepts move i of a record does not depend on who asks:
+// it is found once per record (SgfRecord::legal_prefix, one device replay when the record is first
+// used).  So next() / reload() only RECORD what the board owes -- a reset with the record's handicap
+// and a run of consecutive record moves (PendingOp) -- and the GameContext sends that, for all
+// replays of a batch, inside the one launch that extracts the batch (goenv_offline_batch).
 #pragma once
 
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -114,6 +121,16 @@ class SgfCorpus {
   }
 };
 
+// What a replay's board on the device still owes: reset + handicap, then `count` consecutive moves of
+// `rec` from index `from`.
+struct PendingOp {
+  bool reset = false;
+  int handi = 0;
+  const SgfRecord* rec = nullptr;
+  int from = 0, count = 0;
+  bool empty() const { return !reset && count == 0; }
+};
+
 // One replay: a record, a position in it and a board on the device.
 class OfflineLoader {
  public:
@@ -147,19 +164,15 @@ class OfflineLoader {
     }
   }
 
-  // --- OfflineLoader::next (offpolicy_loader.cc:120-126), split so the common case can be
-  // batched across replays: begin_next() returns the action to forward on the device, or -100
-  // when the whole call was served by the slow path already; end_next(legal) finishes it.
-  int begin_next() {
-    if (need_reload()) {
-      reload();
-      const bool ok = env_->forward_one(board_, curr_move());
-      finish_forward(ok);
-      return -100;
-    }
-    return curr_move();
+  // OfflineLoader::next (offpolicy_loader.cc:120-126): host bookkeeping only
+  void next() {
+    if (need_reload()) reload();
+    finish_forward(forward());
   }
-  void end_next(bool legal) { finish_forward(legal); }
+
+  // what the board owes since it was last brought up to date; the caller sends it and clears it
+  const PendingOp& pending() const { return pend_; }
+  void clear_pending() { pend_ = PendingOp(); }
 
  private:
   OfflineOptions opt_;
@@ -173,7 +186,22 @@ class OfflineLoader {
   int game_loaded_ = 0;
   int ply_ = 1;
 
-  int curr_move() const { return idx_ < (int)rec_->moves.size() ? rec_->moves[idx_] : -1; }
+  PendingOp pend_;
+
+  // s().forward(curr().GetCoord()): legality is the record's (legal_prefix); an accepted move is owed
+  bool forward() {
+    if (idx_ >= (int)rec_->moves.size()) {   // past the last node the iterator yields a pass: always legal
+      throw std::range_error("offline loader: forward past the end of a record (num_future_actions = 0?)");
+    }
+    if (idx_ >= rec_->legal_prefix) return false;
+    owe(1);
+    return true;
+  }
+  void owe(int n) {
+    if (n <= 0) return;
+    if (pend_.count == 0) { pend_.rec = rec_; pend_.from = idx_; }
+    pend_.count += n;
+  }
 
   bool need_reload() const {  // offpolicy_loader.cc:115-118
     const bool done = idx_ >= (int)rec_->moves.size();
@@ -192,8 +220,7 @@ class OfflineLoader {
     while (count > 0) {
       if (need_reload()) {
         reload();
-        const bool ok = env_->forward_one(board_, curr_move());
-        finish_forward(ok);
+        finish_forward(forward());
         --count;
         continue;
       }
@@ -205,7 +232,8 @@ class OfflineLoader {
         if (done || left < opt_.num_future_actions || (opt_.move_cutoff >= 0 && at >= opt_.move_cutoff)) break;
         ++run;
       }
-      const int applied = env_->replay_one(board_, rec_->moves.data() + idx_, run);
+      const int applied = std::max(0, std::min(run, rec_->legal_prefix - idx_));
+      owe(applied);
       idx_ += applied;
       ply_ += applied;
       count -= applied;
@@ -224,7 +252,11 @@ class OfflineLoader {
       idx_ = 0;
       if (rec_->num_moves < 10 || rec_->board_size != GOENV_BOARD_SIZE) continue;
       if (need_reload()) continue;
-      env_->reset_one(board_, rec_->handi);
+      if (rec_->legal_prefix < 0) rec_->legal_prefix = env_->count_legal_prefix(rec_->handi, rec_->moves);
+      pend_ = PendingOp();          // whatever the board owed is void: it starts over
+      pend_.reset = true;
+      pend_.handi = rec_->handi;
+      pend_.rec = rec_;
       ply_ = 1;
       ++game_loaded_;
       const float ratio = game_loaded_ == 1 ? opt_.start_ratio_pre_moves : opt_.ratio_pre_moves;

@@ -35,6 +35,10 @@ struct SgfRecord {
   std::vector<int16_t> moves; // every node after the header, as actions (-1 pass)
   std::vector<uint8_t> players;  // 1 black, 2 white, 0 none, per node
   int num_moves = 0;          // Sgf::NumMoves()
+  // How many of `moves` GoState::forward accepts when the record is replayed from its start (handicap
+  // placed): a property of the record, found by one device replay when a loader first uses it
+  // (DeviceEnv::count_legal_prefix); -1 = not yet known.  Host bookkeeping only.
+  mutable int legal_prefix = -1;
 };
 
 namespace detail {

@@ -761,6 +761,120 @@ __global__ __launch_bounds__(64 * NW) void k_replay(PlyParams P, const int16_t* 
   if (napplied && g.tid == 0) napplied[b] = cnt;
 }
 
+// One offline (SGF replay) batch in ONE launch: the device half of OfflineLoader's reload / next / extract
+// for every row (go/offpolicy_loader.cc:70-108,120-145).  Row b is ROW_W(k) int32 words of a staging block
+// that the host packed (device memory or pinned host memory, read in place):
+//   [0] board  [1] op = aug | reset << 3 | handicap << 4 | nmoves << 8  [2] offset of the row's moves (int16
+//   units from `moves`)  [3] reserved  [4..12) the eight labels in goenv_sample_out order
+//   [12..12 + 2k) offline_a, k int64
+// The board is reset (ClearBoard + HandicapTable::Apply, as k_reset) when the op says so, the row's moves
+// are applied with GoState::forward semantics (the host knows them to be legal: every record is replayed
+// once when it is first loaded; a move the device rejects all the same stops the row and is counted in
+// *bad_moves), then the planes of the position under the row's D4 code, its legal mask and the labels go
+// straight into the batch tensors.
+constexpr int OFFLINE_ROW_HEAD = 12;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_offline(PlyParams P, const int32_t* __restrict__ rows, int row_w, int k_future,
+                                                     const int16_t* __restrict__ moves, int64_t* offline_a_out,
+                                                     int32_t* bad_moves) {
+  __shared__ BoardLds<NW> L;
+  if ((int)blockIdx.x >= P.n) return;
+  const int b = xcd_row(blockIdx.x, P.n, P.xcd_map);
+  Geo<NW> g;
+  geo_init(g);
+  constexpr int K = Geo<NW>::K;
+  const int32_t* row = rows + (size_t)b * row_w;
+  const int board = __builtin_amdgcn_readfirstlane(row[0]);
+  const uint32_t op = (uint32_t)__builtin_amdgcn_readfirstlane(row[1]);
+  const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane(row[2]);
+  // labels: one lane per word, requested before anything else so that the trip to the staging block
+  // (PCIe when it is host memory) overlaps the record load
+  int32_t label = 0;
+  if (g.tid < 8 + 2 * k_future) label = row[4 + g.tid];
+  if (board < 0 || board >= P.n_total) return;
+  const int aug = (int)(op & 7u);
+  const bool reset = (op >> 3) & 1u;
+  const int handi = (int)((op >> 4) & 15u);
+  const int n = (int)(op >> 8);
+  BoardRec* rec = P.state + board;
+  Scalars s;
+  uint32_t lab[K], lastp[K];
+  Masks m;
+  Own<NW> o;
+  float hv_pre[K];
+  int pre_ply = -1;
+  if (reset) {
+    load_scalars(rec, s);
+    const int game = s.game, seqtot = s.seqtot;
+    clear_board_lds(L, g, lab, lastp);
+    clear_scalars(s);
+    s.game = game;
+    s.seqtot = seqtot;
+    if (handi >= 2 && handi <= 9) {
+      for (int j = 0; j < 10; ++j) {
+        const int e = c_handi_sets[handi][j];
+        if (e < 0) break;
+        const int p = c_handi_xy[e][0] * BS + c_handi_xy[e][1];
+        bool ok = s.ply <= 1 && move_is_legal(L, s, p, S_BLACK);   // PlaceHandicap, go/board.cc:48-64
+        ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;
+        if (ok) {
+          apply_move(L, g, lab, lastp, s, p, S_BLACK);
+          s.ply = 1;
+          s.l1 = s.l2 = s.l3 = s.l4 = -1;
+        }
+      }
+    }
+    move_masks(L, g, lab, s, s.next, o);
+    gather_masks(L, g, o, m);
+    GO_UNROLL
+    for (int k = 0; k < K; ++k) hv_pre[k] = 0.f;
+  } else {
+    load_record(rec, L, g, lab, lastp, s, m);
+    own_from_masks(g, m, o);
+    if (P.feat && n == 1) {   // the common row: one move, history values requested with the record
+      pre_ply = s.ply + 1;
+      history_preload(g, lastp, pre_ply, P.lut, hv_pre);
+    } else {
+      GO_UNROLL
+      for (int k = 0; k < K; ++k) hv_pre[k] = 0.f;
+    }
+  }
+  int cnt = 0;
+  bool dirty = reset;
+  for (; cnt < n; ++cnt) {  // bounded by the host-supplied count
+    const int a = ply_body<NW, false, false>(L, g, lab, lastp, s, m, o, P, board, (long long)moves[(size_t)off + cnt]);
+    if (a == -4) break;
+    dirty = true;
+    if (cnt + 1 < n) {      // the next move's TryPlay needs this position's masks; the last one's come after the planes
+      move_masks(L, g, lab, s, s.next, o);
+      gather_masks(L, g, o, m);
+    }
+  }
+  if (cnt < n) {
+    if (g.tid == 0 && bad_moves) atomicAdd(bad_moves, 1);
+    pre_ply = -1;
+  }
+  // labels (GameState fields, go/go_game_specific.h:59-114), written as the host computed them
+  {
+    const goenv_sample_out& o8 = P.meta;
+    int32_t* dst32[8] = {o8.id, o8.seq, o8.game_counter, nullptr, o8.move_idx, o8.winner, o8.aug_code, o8.game_record_idx};
+    GO_UNROLL
+    for (int i = 0; i < 8; ++i)
+      if (g.tid == i && dst32[i]) dst32[i][b] = label;
+    if (g.tid == 3 && o8.last_terminal) o8.last_terminal[b] = (int8_t)label;
+    if (offline_a_out && g.tid >= 8 && g.tid < 8 + 2 * k_future)
+      reinterpret_cast<int32_t*>(offline_a_out)[(size_t)b * 2 * k_future + (g.tid - 8)] = label;
+  }
+  if (P.feat) {
+    float* out = P.feat + (size_t)b * GOENV_FEAT_FLOATS;
+    if (P.zero_first & 2) write_features<NW, true, true>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1);
+    else write_features<NW, true, false>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1);
+  }
+  if (cnt > 0 && cnt == n) move_masks(L, g, lab, s, s.next, o);   // (a rejected move left `o` at the position's masks)
+  if (dirty) store_board(rec, g, lab, lastp, o, s);
+  if (P.legal) write_legal(g, o, P.legal + (size_t)b * NPTS);
+}
+
 // Record copies between slots of one context: what a host-side tree search needs to branch
 // (child slot = copy of the parent slot, then one goenv_ply_sel on the children).
 __global__ __launch_bounds__(128) void k_copy_boards(BoardRec* state, int n_total, const int32_t* src,
@@ -916,6 +1030,13 @@ struct goenv_ctx {
   hipStream_t part_stream[GOENV_MAX_PARTS];  // goenv_ply_repeat_parts; created on first use
   hipEvent_t part_event[GOENV_MAX_PARTS + 1];
   int parts_ready;
+  // goenv_stage_acquire: ring of pinned host blocks that kernels read in place
+  void* stage_host[GOENV_STAGE_SLOTS];
+  size_t stage_cap[GOENV_STAGE_SLOTS];
+  hipEvent_t stage_event[GOENV_STAGE_SLOTS];
+  int stage_busy[GOENV_STAGE_SLOTS];   // an event has been recorded after the slot's last reader
+  int stage_next;
+  int32_t* bad_moves;                  // device counter of goenv_offline_batch rows that hit a rejected move
 };
 
 // The standalone feature kernel has no rules phase that staggers its waves' stores: mid-size
@@ -1072,6 +1193,11 @@ int goenv_destroy(goenv_ctx* c) {
   if (c->sampled) (void)hipFree(c->sampled);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
+  for (int i = 0; i < GOENV_STAGE_SLOTS; ++i) {
+    if (c->stage_host[i]) (void)hipHostFree(c->stage_host[i]);
+    if (c->stage_event[i]) (void)hipEventDestroy(c->stage_event[i]);
+  }
+  if (c->bad_moves) (void)hipFree(c->bad_moves);
   if (c->parts_ready) {
     for (int i = 0; i < GOENV_MAX_PARTS; ++i) (void)hipStreamDestroy(c->part_stream[i]);
     for (int i = 0; i <= GOENV_MAX_PARTS; ++i) (void)hipEventDestroy(c->part_event[i]);
@@ -1465,6 +1591,76 @@ int goenv_replay(goenv_ctx* c, const int32_t* idx, int first, int count, const i
   P.max_ply = 0;  // a replayed record is not subject to the playout ply cap
   GO_LAUNCH(pick_nw(c, count), k_replay, count, S(stream), P, moves, stride, nmoves, napplied_out);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- offline (SGF replay) batches -----------------------------------------------------------------
+// Staging ring: GOENV_STAGE_SLOTS pinned host blocks, handed out in turn.  A block is written by the host,
+// read IN PLACE by the one kernel launched with it (no copy engine, no extra stream operation in front
+// of the kernel: the rows of a batch are a few KB) and handed out again only after that kernel is done.
+int goenv_stage_acquire(goenv_ctx* c, size_t bytes, void** host_block) {
+  if (!c || !host_block) return fail("goenv_stage_acquire: NULL argument");
+  ON_DEVICE_OF(c);
+  const int i = c->stage_next;
+  if (c->stage_busy[i]) {   // the kernel that read this block last (GOENV_STAGE_SLOTS launches ago)
+    HIPCHK(hipEventSynchronize(c->stage_event[i]));
+    c->stage_busy[i] = 0;
+  }
+  if (c->stage_cap[i] < bytes) {
+    if (c->stage_host[i]) HIPCHK(hipHostFree(c->stage_host[i]));
+    c->stage_host[i] = nullptr; c->stage_cap[i] = 0;
+    const size_t cap = bytes < 65536 ? 65536 : bytes + bytes / 2;
+    HIPCHK(hipHostMalloc(&c->stage_host[i], cap, hipHostMallocDefault));
+    c->stage_cap[i] = cap;
+  }
+  if (!c->stage_event[i]) HIPCHK(hipEventCreateWithFlags(&c->stage_event[i], hipEventDisableTiming));
+  *host_block = c->stage_host[i];
+  return 0;
+}
+
+// marks the block acquired last as read by everything enqueued on `stream` so far
+static int stage_commit(goenv_ctx* c, const void* block, void* stream) {
+  const int i = c->stage_next;
+  if (block != c->stage_host[i]) return 0;   // not a ring block (device memory, or the caller's own)
+  HIPCHK(hipEventRecord(c->stage_event[i], S(stream)));
+  c->stage_busy[i] = 1;
+  c->stage_next = (i + 1) % GOENV_STAGE_SLOTS;
+  return 0;
+}
+
+int goenv_offline_batch(goenv_ctx* c, const void* block, int count, int k_future, size_t moves_offset,
+                        float* feat_out, uint8_t* legal_out, const goenv_sample_out* labels, int64_t* offline_a_out,
+                        void* stream) {
+  if (!c || !block) return fail("goenv_offline_batch: NULL argument");
+  if (count < 0 || count > c->n) return fail("goenv_offline_batch: count out of range");
+  if (k_future < 0 || k_future > GOENV_MAX_FUTURE) return fail("goenv_offline_batch: k_future out of range");
+  if (moves_offset & 1) return fail("goenv_offline_batch: moves_offset must be even");
+  ON_DEVICE_OF(c);
+  if (count == 0) return stage_commit(c, block, stream);
+  if (!c->bad_moves) {
+    HIPCHK(hipMalloc((void**)&c->bad_moves, sizeof(int32_t)));
+    HIPCHK(hipMemset(c->bad_moves, 0, sizeof(int32_t)));
+  }
+  PlyParams P = make_params(c, 0u, nullptr, nullptr, feat_out, legal_out, nullptr, nullptr);
+  P.n = count;
+  P.max_ply = 0;  // a replayed record is not subject to the playout ply cap
+  P.zero_first = pick_zero_first(c, count);
+  if (labels) P.meta = *labels;
+  const int row_w = OFFLINE_ROW_HEAD + 2 * k_future;
+  const int nw = feat_out ? pick_nw_features(c, count) : pick_nw(c, count);
+  GO_LAUNCH(nw, k_offline, count, S(stream), P, (const int32_t*)block, row_w, k_future,
+            (const int16_t*)((const char*)block + moves_offset), offline_a_out, c->bad_moves);
+  HIPCHK(hipGetLastError());
+  return stage_commit(c, block, stream);
+}
+
+int goenv_offline_bad_moves(goenv_ctx* c, int32_t* out_host, void* stream) {
+  if (!c || !out_host) return fail("goenv_offline_bad_moves: NULL argument");
+  ON_DEVICE_OF(c);
+  *out_host = 0;
+  if (!c->bad_moves) return 0;
+  HIPCHK(hipMemcpyAsync(out_host, c->bad_moves, sizeof(int32_t), hipMemcpyDeviceToHost, S(stream)));
+  HIPCHK(hipStreamSynchronize(S(stream)));
   return 0;
 }
 

@@ -60,6 +60,9 @@ _SIGS = {
     "goenv_get_state_sel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]),
     "goenv_replay": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_void_p]),
+    "goenv_stage_acquire": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "goenv_offline_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t] + [C.c_void_p] * 5),
+    "goenv_offline_bad_moves": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "goenv_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "goenv_host_free": (C.c_int, [C.c_void_p]),
     "goenv_copy_boards": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

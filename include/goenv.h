@@ -312,6 +312,35 @@ int goenv_get_state_sel(goenv_ctx* ctx, const int32_t* idx, int first, int count
 int goenv_replay(goenv_ctx* ctx, const int32_t* idx, int first, int count, const int16_t* moves,
                  int stride, const int32_t* nmoves, int32_t* napplied_out, void* stream);
 
+/* Offline (SGF replay) batches -------------------------------------------------
+ * goenv_offline_batch: the device half of ONE batch of the reference's OfflineLoader
+ * (go/offpolicy_loader.cc) in one launch.  For every row: Reload's Reset + ApplyHandicap
+ * (elf/replay_loader.h:28-35, go/go_state.cc:85-91) when the row says so, then next()'s
+ * s().forward(move) for each of the row's moves (:120-126, and the pre-move loop of after_reload
+ * :94-101), then extract (:128-145): planes under the row's D4 code into feat_out[row], the legal
+ * mask into legal_out[row], and the labels the host computed -- id / seq / game_counter /
+ * last_terminal / move_idx / winner / aug_code / game_record_idx and offline_a[k_future] -- into
+ * `labels` / offline_a_out (device arrays [count] / [count][k_future]; any may be NULL).
+ * `block` is what the host packed: count rows of (12 + 2 k_future) int32 words
+ *   [0] board  [1] aug | reset << 3 | handicap << 4 | nmoves << 8  [2] first move of the row,
+ *   in int16 units from block + moves_offset  [3] 0  [4..12) the eight labels in goenv_sample_out
+ *   order  [12..) offline_a as k_future int64
+ * followed at moves_offset (even) by the rows' moves as int16 actions.  It may be device memory
+ * or a block of the staging ring below, which the kernel reads in place.  Boards of one call must be
+ * distinct.  The caller is expected to pass moves it knows to be legal (a record's legality is a
+ * property of the record: replay it once with goenv_replay when it is loaded); a move the device
+ * rejects all the same stops its row and is counted (goenv_offline_bad_moves, which synchronises).
+ * goenv_stage_acquire: the next block of a ring of GOENV_STAGE_SLOTS pinned host blocks of at least
+ * `bytes` bytes (host pointer; waits until the launch that read this block last has finished).  The
+ * block is taken by the next goenv_offline_batch call that is given it. */
+#define GOENV_STAGE_SLOTS 8
+#define GOENV_MAX_FUTURE 16
+int goenv_stage_acquire(goenv_ctx* ctx, size_t bytes, void** host_block);
+int goenv_offline_batch(goenv_ctx* ctx, const void* block, int count, int k_future, size_t moves_offset,
+                        float* feat_out, uint8_t* legal_out, const goenv_sample_out* labels,
+                        int64_t* offline_a_out, void* stream);
+int goenv_offline_bad_moves(goenv_ctx* ctx, int32_t* out_host, void* stream);
+
 /* goenv_copy_boards: board dst_idx[i] becomes a copy of board src_idx[i] (device int32 [n];
  * the destinations must be distinct and must not appear among the sources of the same call).
  * This is CopyBoard (go/board.h, used by GoState's copy constructor go/go_state.h:47-49) for
