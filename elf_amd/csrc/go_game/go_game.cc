@@ -224,6 +224,8 @@ class GameContext {
         throw std::range_error("MCTS Pick method unknown! " + ts.pick_method);
       tick_ = ts.num_threads + 1;
     }
+    if (offline_ && (opt_.num_future_actions < 0 || opt_.num_future_actions > GOENV_MAX_FUTURE))
+      throw std::range_error("GameOptions.num_future_actions must be in 0.." + std::to_string(GOENV_MAX_FUTURE));
     if (offline_ && !opt_.list_filename.empty()) {
       if (!corpus_.load_list(opt_.list_filename))
         std::cout << "Loading " << opt_.list_filename << " failed!" << std::endl;
@@ -413,6 +415,7 @@ class GameContext {
     if (co_.wait_per_group)
       throw std::range_error("wait_batch error. group_id = -1 while #queue_per_group = " +
                              std::to_string(collectors_.size()));
+    HostTimer t(&host_wait_us_, &host_waits_);
     return wait_impl(-1);
   }
 
@@ -421,11 +424,13 @@ class GameContext {
     if (!co_.wait_per_group || group_id < 0 || group_id >= (int)collectors_.size())
       throw std::range_error("wait_batch error. group_id = " + std::to_string(group_id) +
                              " while #queue_per_group = " + std::to_string(co_.wait_per_group ? collectors_.size() : 0));
+    HostTimer t(&host_wait_us_, &host_waits_);
     return wait_impl(group_id);
   }
 
   void Steps(const Infos& infos) {
     if (infos.gid < 0) return;  // timed-out Wait: nothing to release (comm_template.h:270)
+    HostTimer t(&host_steps_us_, &host_steps_);
     Collector& c = collector(infos.gid);
     if (!c.busy) throw std::range_error("Steps(): collector " + std::to_string(infos.gid) + " has no batch outstanding");
     if (general_) {
@@ -475,6 +480,15 @@ class GameContext {
     d["ply"] = games_[game_idx].ply;
     d["nodes"] = searches_[game_idx]->num_nodes();
     d["root_edges"] = searches_[game_idx]->root_edges();
+    return d;
+  }
+
+  // host time spent inside Wait / Steps since Start (or the last reset): what the GPU is NOT doing
+  py::dict HostTimes(bool reset) {
+    py::dict d;
+    d["wait_us"] = host_wait_us_; d["waits"] = host_waits_;
+    d["steps_us"] = host_steps_us_; d["steps"] = host_steps_;
+    if (reset) { host_wait_us_ = host_steps_us_ = 0; host_waits_ = host_steps_ = 0; }
     return d;
   }
 
@@ -542,6 +556,15 @@ class GameContext {
     size_t rr = 0;
   };
 
+  struct HostTimer {
+    double* acc; long* cnt;
+    std::chrono::steady_clock::time_point t0;
+    HostTimer(double* a, long* c) : acc(a), cnt(c), t0(std::chrono::steady_clock::now()) {}
+    ~HostTimer() { *acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); ++*cnt; }
+  };
+  double host_wait_us_ = 0, host_steps_us_ = 0;
+  long host_waits_ = 0, host_steps_ = 0;
+
   ContextOptions co_;
   GameOptions opt_;
   bool offline_ = false;
@@ -570,6 +593,7 @@ class GameContext {
   int hist_T_ = 1;
   std::map<std::string, DevBuf> ring_;   // key -> ring (s, legal, pi, a, V)
   DevBuf g_rows_, g_stage_s_, g_stage_l_, g_stage_, g_idx_, g_act_, g_pi_, g_status_;
+  std::vector<OfflineLoader*> off_lds_;   // scratch of fill_inputs_offline
 
   static uint64_t clock_seed() {
     using namespace std::chrono;
@@ -610,6 +634,7 @@ class GameContext {
         gs.seq.seq = 0; gs.seq.game_counter += 1; gs.seq.last_terminal = 1;
       }
       gs.sample.aug = 0;  // drawn in wait_impl, at extract time, after Prepare
+      ld.prefetch();      // 76,800 replays do not fit the caches: ask for this one's lines now, use them in Wait
     }
     if (mcts_ && gs.phase == 1) {  // MCTSAI_T::Act: a fresh tree rooted at the game's position
       searches_[g]->begin(g);
@@ -755,15 +780,17 @@ class GameContext {
   }
 
   void fill_inputs(Collector& c) {
+    if (offline_) {
+      fill_inputs_offline(c);
+      return;
+    }
     const int n = (int)c.games.size();
     c.boards.resize(n);
     std::vector<int32_t> aug(n, 0);
     std::vector<int32_t> meta[8];
-    std::vector<int64_t> off_a;
-    const bool host_meta = offline_ || opt_.mode == "online" || mcts_;
+    const bool host_meta = opt_.mode == "online" || mcts_;
     if (host_meta)
       for (auto& m : meta) m.assign(n, 0);
-    if (offline_) off_a.assign((size_t)n * opt_.num_future_actions, 0);
     std::vector<int32_t> mk_src, mk_dst;   // tree search: leaf positions still to be made
     std::vector<int64_t> mk_act;
     for (int r = 0; r < n; ++r) {
@@ -779,20 +806,6 @@ class GameContext {
         meta[0][r] = g; meta[1][r] = ts.seq_of(leaf - 1); meta[2][r] = 0; meta[3][r] = 0;
         ts.bump_seq(leaf - 1);
         meta[4][r] = gs.ply + rq.depth; meta[5][r] = 0; meta[6][r] = 0; meta[7][r] = -1;
-      } else if (offline_) {
-        OfflineLoader& ld = *gs.loaders[gs.sample.loader];
-        c.boards[r] = ld.board();
-        // Prepare (elf/ai_comm.h:62-67), then extract (offpolicy_loader.cc:128-145)
-        meta[1][r] = gs.seq.seq; meta[2][r] = gs.seq.game_counter; meta[3][r] = gs.seq.last_terminal;
-        gs.seq.seq += 1; gs.seq.last_terminal = 0;
-        meta[0][r] = g;
-        meta[7][r] = ld.curr_game();
-        meta[4][r] = ld.ply();
-        meta[5][r] = ld.winner_label();
-        gs.sample.aug = ld.draw_aug_code();
-        meta[6][r] = gs.sample.aug;
-        aug[r] = gs.sample.aug;
-        ld.future_actions(gs.sample.aug, &off_a[(size_t)r * opt_.num_future_actions]);
       } else {
         c.boards[r] = g;
         if (host_meta) {  // online: DirectPredictAI / HumanPlayer extract, go/go_ai.h:79-87,106-113
@@ -818,7 +831,7 @@ class GameContext {
     for (int r = 1; r < n; ++r)
       if (c.boards[r] != c.boards[0] + r) { c.contiguous = false; break; }
     const int32_t* d_idx = nullptr;
-    if (!c.contiguous && !offline_) {
+    if (!c.contiguous) {
       c.idx.ensure(env_->ctx(), (size_t)n * 4);
       env_->h2d(c.idx.get(), c.boards.data(), (size_t)n * 4);
       d_idx = c.idx.as<int32_t>();
@@ -843,29 +856,8 @@ class GameContext {
     // the device always advances seq in selfplay mode, registered or not
     const goenv_sample_out* meta_arg = host_meta ? nullptr : &so;
     (void)want_dev_meta;
-    if (offline_) {
-      // ONE launch for the whole batch: what every replay's board owes (the move of its last next(), or a
-      // reload's reset + handicap + pre-moves), the planes under the sample's D4 code, and the labels the
-      // host computed above, straight into the registered device tensors (go/offpolicy_loader.cc:120-145)
-      std::vector<OfflineLoader*> lds(n);
-      for (int r = 0; r < n; ++r) lds[r] = games_[c.games[r]].loaders[games_[c.games[r]].sample.loader].get();
-      goenv_sample_out lab;
-      std::memset(&lab, 0, sizeof(lab));
-      void** fields[8] = {(void**)&lab.id, (void**)&lab.seq, (void**)&lab.game_counter, (void**)&lab.last_terminal,
-                          (void**)&lab.move_idx, (void**)&lab.winner, (void**)&lab.aug_code, (void**)&lab.game_record_idx};
-      for (int k = 0; k < 8; ++k) {
-        auto it = c.input.find(kMetaKeys[k]);
-        if (it != c.input.end() && it->second.device) *fields[k] = it->second.p;
-      }
-      auto ita = c.input.find("offline_a");
-      int64_t* d_offa = (ita != c.input.end() && ita->second.device) ? (int64_t*)ita->second.p : nullptr;
-      const int32_t* mp[8];
-      for (int k = 0; k < 8; ++k) mp[k] = meta[k].data();
-      offline_launch(lds, aug.data(), mp, off_a.data(), d_s, d_l, &lab, d_offa);
-    } else {
-      chk(goenv_collect_sel(env_->ctx(), d_idx, c.contiguous ? c.boards[0] : 0, n, d_aug, d_s, d_l, meta_arg,
-                            env_->stream()), "goenv_collect_sel");
-    }
+    chk(goenv_collect_sel(env_->ctx(), d_idx, c.contiguous ? c.boards[0] : 0, n, d_aug, d_s, d_l, meta_arg,
+                          env_->stream()), "goenv_collect_sel");
     bool need_sync = false;
     auto flush = [&](const std::string& key, DevBuf& stage, bool staged, size_t bytes) {
       if (!staged) return;
@@ -879,7 +871,6 @@ class GameContext {
       for (int k = 0; k < 8; ++k) {
         auto it = c.input.find(kMetaKeys[k]);
         if (it == c.input.end()) continue;
-        if (offline_ && it->second.device) continue;   // written by the batch's launch
         if (k == 3) {
           std::vector<int8_t> lt(n);
           for (int r = 0; r < n; ++r) lt[r] = (int8_t)meta[3][r];
@@ -888,11 +879,100 @@ class GameContext {
           put(it->second, meta[k].data(), (size_t)n * 4);
         }
       }
-      auto it = c.input.find("offline_a");
-      if (it != c.input.end() && offline_ && !it->second.device) put(it->second, off_a.data(), off_a.size() * 8);
     }
     // host-resident tensors must be complete when Wait returns; device tensors are stream-ordered
     if (need_sync) env_->sync();
+  }
+
+  // Offline batches: AI::Act up to the batch hand-over for every replay of the batch -- Prepare
+  // (elf/ai_comm.h:62-67) and OfflineLoader::extract (go/offpolicy_loader.cc:128-145) -- packed in ONE
+  // pass straight into a block of the library's pinned staging ring, then ONE launch
+  // (goenv_offline_batch): what every replay's board owes (the move of its last next(), or a reload's
+  // reset + handicap + pre-moves), the planes under the sample's D4 code, and the labels into the
+  // registered device tensors.  No allocation, no copy engine, no wait.
+  void fill_inputs_offline(Collector& c) {
+    const int n = (int)c.games.size();
+    const int k = opt_.num_future_actions;
+    const int row_w = 12 + 2 * k;
+    c.boards.resize(n);
+    off_lds_.resize(n);
+    size_t total_moves = 0;
+    for (int r = 0; r < n; ++r) {
+      GameSlot& gs = games_[c.games[r]];
+      OfflineLoader* ld = gs.loaders[gs.sample.loader].get();
+      off_lds_[r] = ld;
+      total_moves += (size_t)ld->pending().count;
+    }
+    const size_t moves_off = (size_t)n * row_w * 4;
+    void* block = nullptr;
+    chk(goenv_stage_acquire(env_->ctx(), moves_off + total_moves * 2 + 16, &block), "goenv_stage_acquire");
+    int32_t* rows = static_cast<int32_t*>(block);
+    int16_t* mv = reinterpret_cast<int16_t*>(static_cast<char*>(block) + moves_off);
+    size_t at = 0;
+    for (int r = 0; r < n; ++r) {
+      const int g = c.games[r];
+      GameSlot& gs = games_[g];
+      OfflineLoader& ld = *off_lds_[r];
+      int32_t* row = rows + (size_t)r * row_w;
+      c.boards[r] = ld.board();
+      const int aug = ld.draw_aug_code();
+      gs.sample.aug = aug;
+      const PendingOp& op = ld.pending();
+      row[0] = ld.board();
+      row[1] = (int32_t)((uint32_t)aug | (op.reset ? 8u : 0u) | ((uint32_t)(op.handi & 15) << 4) | ((uint32_t)op.count << 8));
+      row[2] = (int32_t)at;
+      row[3] = 0;
+      row[4] = g; row[5] = gs.seq.seq; row[6] = gs.seq.game_counter; row[7] = gs.seq.last_terminal;
+      gs.seq.seq += 1; gs.seq.last_terminal = 0;
+      row[8] = ld.ply(); row[9] = ld.winner_label(); row[10] = aug; row[11] = ld.curr_game();
+      ld.future_actions(aug, reinterpret_cast<int64_t*>(row + 12));
+      if (op.count > 0) {
+        std::memcpy(mv + at, op.rec->moves.data() + op.from, (size_t)op.count * 2);
+        at += (size_t)op.count;
+      }
+      ld.clear_pending();
+    }
+    bool st_s = false, st_l = false;
+    float* d_s = out_ptr<float>(c, "s", c.stage_s, (size_t)n * GOENV_FEAT_FLOATS * 4, &st_s);
+    uint8_t* d_l = out_ptr<uint8_t>(c, "legal", c.stage_legal, (size_t)n * GOENV_NUM_POINTS, &st_l);
+    goenv_sample_out lab;
+    std::memset(&lab, 0, sizeof(lab));
+    void** fields[8] = {(void**)&lab.id, (void**)&lab.seq, (void**)&lab.game_counter, (void**)&lab.last_terminal,
+                        (void**)&lab.move_idx, (void**)&lab.winner, (void**)&lab.aug_code, (void**)&lab.game_record_idx};
+    const Slot* host_slot[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int f = 0; f < 8; ++f) {
+      auto it = c.input.find(kMetaKeys[f]);
+      if (it == c.input.end()) continue;
+      if (it->second.device) *fields[f] = it->second.p;
+      else host_slot[f] = &it->second;
+    }
+    int64_t* d_offa = nullptr;
+    auto ita = c.input.find("offline_a");
+    if (ita != c.input.end()) {
+      if (ita->second.device) d_offa = (int64_t*)ita->second.p;
+      else host_slot[8] = &ita->second;
+    }
+    // host-resident label tensors (the reference's pinned buffers): plain copies out of the block, before
+    // the launch hands the block to the device
+    for (int f = 0; f < 8; ++f) {
+      if (!host_slot[f]) continue;
+      if (f == 3) {
+        int8_t* dst = static_cast<int8_t*>(host_slot[f]->p);
+        for (int r = 0; r < n; ++r) dst[r] = (int8_t)rows[(size_t)r * row_w + 4 + f];
+      } else {
+        int32_t* dst = static_cast<int32_t*>(host_slot[f]->p);
+        for (int r = 0; r < n; ++r) dst[r] = rows[(size_t)r * row_w + 4 + f];
+      }
+    }
+    if (host_slot[8]) {
+      int64_t* dst = static_cast<int64_t*>(host_slot[8]->p);
+      for (int r = 0; r < n; ++r) std::memcpy(dst + (size_t)r * k, rows + (size_t)r * row_w + 12, (size_t)k * 8);
+    }
+    chk(goenv_offline_batch(env_->ctx(), block, n, k, moves_off, d_s, d_l, &lab, d_offa, env_->stream()),
+        "goenv_offline_batch");
+    if (st_s) env_->d2h(c.input["s"].p, c.stage_s.get(), (size_t)n * GOENV_FEAT_FLOATS * 4);
+    if (st_l) env_->d2h(c.input["legal"].p, c.stage_legal.get(), (size_t)n * GOENV_NUM_POINTS);
+    if (st_s || st_l) env_->sync();   // host-resident tensors must be complete when Wait returns
   }
 
   // small host-produced field -> registered tensor (host: plain copy; device: staged H2D)
@@ -1527,6 +1607,7 @@ PYBIND11_MODULE(go_game, m) {
       .def("SetStream", &GameContext::SetStream)
       .def("Stats", &GameContext::Stats)
       .def("StatsPtr", &GameContext::StatsPtr)
+      .def("HostTimes", &GameContext::HostTimes, py::arg("reset") = false)
       .def("SearchInfo", &GameContext::SearchInfo);
 
   // the host-side tree search by itself (CPU tests drive it against a board engine of their own)
@@ -1584,6 +1665,14 @@ PYBIND11_MODULE(go_game, m) {
     d["board_size"] = r.board_size;
     d["moves"] = std::vector<int>(r.moves.begin(), r.moves.end());
     return d;
+  });
+  // the offline loader's own Mersenne twister against the standard engine (same seeds as GoGame uses)
+  m.def("mt19937_matches_std", [](uint32_t seed, int draws) {
+    Mt19937 a(seed);
+    std::mt19937 b(seed);
+    for (int i = 0; i < draws; ++i)
+      if (a() != (uint32_t)b()) return false;
+    return true;
   });
   m.def("aug_action", &goenv_aug_action);        // BoardFeature::Coord2Action, go/board_feature.h:62-65
   m.def("aug_action_inv", &goenv_aug_action_inv);  // BoardFeature::Action2Coord, :67-71

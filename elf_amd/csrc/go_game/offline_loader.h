@@ -121,6 +121,46 @@ class SgfCorpus {
   }
 };
 
+// std::mt19937 restated (same recurrence, tempering and seeding, so the same stream: checked against the
+// standard engine by go_game.mt19937_matches_std) with its position index in front of the state words.
+// A context holds one engine per replay -- 76,800 of them, 190 MB, at 256 games x 300 replays -- and a
+// batch draws from 256 random ones: the index and the word it points at are the two cache lines a draw
+// touches, and prefetch() can name both (the standard engine keeps its index behind the 2.5-KB state).
+class Mt19937 {
+ public:
+  explicit Mt19937(uint32_t seed = 5489u) { this->seed(seed); }
+  void seed(uint32_t s) {
+    x_[0] = s;
+    for (uint32_t i = 1; i < N; ++i) x_[i] = 1812433253u * (x_[i - 1] ^ (x_[i - 1] >> 30)) + i;
+    p_ = N;
+  }
+  uint32_t operator()() {
+    if (p_ >= N) refill();
+    uint32_t y = x_[p_++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+  }
+  void prefetch() const {
+    __builtin_prefetch(&p_);
+    __builtin_prefetch(&x_[p_ < N ? p_ : 0]);
+  }
+
+ private:
+  static constexpr uint32_t N = 624, M = 397;
+  uint32_t p_ = N;
+  uint32_t x_[N];
+  void refill() {
+    for (uint32_t i = 0; i < N; ++i) {
+      const uint32_t y = (x_[i] & 0x80000000u) | (x_[(i + 1) % N] & 0x7fffffffu);
+      x_[i] = x_[(i + M) % N] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    p_ = 0;
+  }
+};
+
 // What a replay's board on the device still owes: reset + handicap, then `count` consecutive moves of
 // `rec` from index `from`.
 struct PendingOp {
@@ -158,16 +198,35 @@ class OfflineLoader {
     for (int i = 0; i < opt_.num_future_actions; ++i) {
       const int at = idx_ + i;
       const int mv = at < (int)rec_->moves.size() ? rec_->moves[at] : -3;
-      int a = mv >= 0 ? goenv_aug_action(aug, mv) : -1;
+      int a = mv >= 0 ? d4_table()[(aug & 7) * GOENV_NUM_POINTS + mv] : -1;
       if (a < 0 || a >= GOENV_NUM_POINTS) a = 0;  // "invalid action!" clamp, :162-169
       out[i] = a;
     }
+  }
+
+  // Coord2Action of every (D4 code, point) (go/board_feature.h:62-65), tabulated once
+  static const int16_t* d4_table() {
+    static const std::vector<int16_t> t = [] {
+      std::vector<int16_t> v(8 * GOENV_NUM_POINTS);
+      for (int c = 0; c < 8; ++c)
+        for (int p = 0; p < GOENV_NUM_POINTS; ++p) v[c * GOENV_NUM_POINTS + p] = (int16_t)goenv_aug_action(c, p);
+      return v;
+    }();
+    return t.data();
   }
 
   // OfflineLoader::next (offpolicy_loader.cc:120-126): host bookkeeping only
   void next() {
     if (need_reload()) reload();
     finish_forward(forward());
+  }
+
+  // the lines the next sample of this replay will touch (called when the replay is chosen, a few
+  // microseconds before it is used)
+  void prefetch() const {
+    __builtin_prefetch(this);
+    __builtin_prefetch(reinterpret_cast<const char*>(this) + 64);
+    rng_.prefetch();
   }
 
   // what the board owes since it was last brought up to date; the caller sends it and clears it
@@ -179,14 +238,13 @@ class OfflineLoader {
   SgfCorpus* corpus_;
   DeviceEnv* env_;
   int board_;
-  std::mt19937 rng_;
   const SgfRecord* rec_ = nullptr;
   int idx_ = 0;          // Sgf::iterator::_move_idx
   int curr_game_ = 0;
   int game_loaded_ = 0;
   int ply_ = 1;
-
   PendingOp pend_;
+  Mt19937 rng_;          // last: the fields above share two cache lines (prefetch())
 
   // s().forward(curr().GetCoord()): legality is the record's (legal_prefix); an accepted move is owed
   bool forward() {

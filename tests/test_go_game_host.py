@@ -165,3 +165,11 @@ def test_tar_corpus_lists_and_reads_like_the_list_file(go):
         a, b = go.corpus_record(tar, i), go.corpus_record(lst, i)
         assert a == b and a["moves"] == ref[nm]["moves"] and a["num_moves"] == ref[nm]["num_moves"], nm
     assert go.corpus_names(os.path.join(GOLDEN, "corpus", "missing.tar")) == []
+
+
+def test_own_mersenne_twister_gives_the_standard_stream(go):
+    """OfflineLoader keeps one engine per replay; its own Mt19937 (index in front of the state, so the
+    two lines a draw touches can be prefetched) must give std::mt19937's stream for the seeds GoGame
+    derives (go/game.cc:51), across several refills of the state."""
+    for seed in (0, 1, 7, 5489, 13773 + 7, 2 ** 31, 2 ** 32 - 1, 997 * 255 * 299 + 13773 * 299 + 7 + 7):
+        assert go.mt19937_matches_std(seed & 0xFFFFFFFF, 3000), seed

@@ -60,6 +60,8 @@ def drive(go, games, batches, make_buffer, sync, warm=20):
     for i in range(warm + batches):
         if i == warm:
             sync()
+            if hasattr(gc, "HostTimes"):
+                gc.HostTimes(True)
             t0, n = time.perf_counter(), 0
         infos = gc.Wait(0)
         n += len(infos.s)
@@ -85,8 +87,11 @@ def run_ours(args):
 
     gc, bufs, n, dt = drive(go_game, args.games, args.batches, host_buffer if args.host else dev_buffer,
                             torch.cuda.synchronize)
+    ht = gc.HostTimes()
     gc.Stop()
-    return {"samples": n, "seconds": dt, "samples_per_s": n / dt, "tensors": "host" if args.host else "device"}
+    return {"samples": n, "seconds": dt, "samples_per_s": n / dt, "tensors": "host" if args.host else "device",
+            "us_per_batch": dt / args.batches * 1e6, "host_wait_us_per_batch": ht["wait_us"] / max(1, ht["waits"]),
+            "host_steps_us_per_batch": ht["steps_us"] / max(1, ht["steps"])}
 
 
 def run_reference_child(args):
