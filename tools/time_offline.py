@@ -10,7 +10,7 @@ offline_a + labels), samples per second.
               Run as a child process that leaves with os._exit (its teardown blocks).
 
 Same corpus (tests/golden/corpus/train.lst), same GameOptions.  Usage:
-    tools/time_offline.py [--games 256] [--batches 200] [--host] [--skip-reference]"""
+    tools/time_offline.py [--games 256] [--batches 200] [--our-batches 4000] [--host] [--skip-reference]"""
 import argparse
 import glob
 import json
@@ -85,12 +85,13 @@ def run_ours(args):
         v = np.zeros(info.sz, dtype=NP_TYPES[info.type])
         return v, v.ctypes.data, v.nbytes
 
-    gc, bufs, n, dt = drive(go_game, args.games, args.batches, host_buffer if args.host else dev_buffer,
+    batches = args.our_batches if not args.host else min(args.our_batches, 400)
+    gc, bufs, n, dt = drive(go_game, args.games, batches, host_buffer if args.host else dev_buffer,
                             torch.cuda.synchronize)
     ht = gc.HostTimes()
     gc.Stop()
     return {"samples": n, "seconds": dt, "samples_per_s": n / dt, "tensors": "host" if args.host else "device",
-            "us_per_batch": dt / args.batches * 1e6, "host_wait_us_per_batch": ht["wait_us"] / max(1, ht["waits"]),
+            "batches": batches, "us_per_batch": dt / batches * 1e6, "host_wait_us_per_batch": ht["wait_us"] / max(1, ht["waits"]),
             "host_steps_us_per_batch": ht["steps_us"] / max(1, ht["steps"])}
 
 
@@ -116,7 +117,8 @@ def run_reference_child(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--games", type=int, default=256)
-    ap.add_argument("--batches", type=int, default=200)
+    ap.add_argument("--batches", type=int, default=200, help="timed batches of the reference module")
+    ap.add_argument("--our-batches", type=int, default=4000, help="timed batches of this build (16 us each: 200 would be 3 ms)")
     ap.add_argument("--host", action="store_true")
     ap.add_argument("--skip-reference", action="store_true")
     ap.add_argument("--reference-child", action="store_true", help=argparse.SUPPRESS)
