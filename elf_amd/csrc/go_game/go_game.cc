@@ -310,6 +310,12 @@ class GameContext {
     if (e.p == 0 || T < 1 || T * want != e.byte_size || (int)T > std::max(1, co_.T))
       throw std::range_error("AddTensor: \"" + e.key + "\" needs a buffer of T x " + std::to_string(want) +
                              " bytes with T in 1..ContextOptions.T, got " + std::to_string(e.byte_size));
+    // a group is offered a sample once the game's history holds hist_len entries (CondPerGroupT::Check,
+    // elf/comm_template.h:88): a tensor with more entries than that would be padded (elf/hist.h:90-98) with
+    // rows this build does not reproduce -- ask for hist_len >= T instead
+    if ((int)T > std::max(1, c.gstat.hist_len))
+      throw std::range_error("AddTensor: \"" + e.key + "\" holds T = " + std::to_string(T) + " entries but the group's hist_len is " +
+                             std::to_string(c.gstat.hist_len) + "; set GroupStat.hist_len >= T");
     Slot s;
     s.p = reinterpret_cast<void*>(e.p);
     s.bytes = e.byte_size;
@@ -1168,7 +1174,13 @@ class GameContext {
     for (const auto& c : collectors_)
       for (const auto* m : {&c->input, &c->reply})
         for (const auto& kv : *m)
-          if (ring_key(kv.first)) ring_[kv.first].ensure(env_->ctx(), rows * kv.second.row);
+          if (ring_key(kv.first) && !ring_.count(kv.first)) {
+            // cleared once: a sample that no group takes (history gate) acts on the newest entry's reply,
+            // which nobody has written -- the reference's GameState starts zeroed too (`a` = 0, `pi` = 0)
+            DevBuf& rb = ring_[kv.first];
+            rb.ensure(env_->ctx(), rows * kv.second.row);
+            chk(goenv_memset(env_->ctx(), rb.get(), 0, rows * kv.second.row, env_->stream()), "goenv_memset");
+          }
   }
 
   int ring_row(const GameSlot& gs, int g, int back) const {

@@ -7,7 +7,6 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
-#include <rccl/rccl.h>   // types and enums only: librccl.so is opened at the first collective call
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1025,8 +1024,7 @@ struct goenv_ctx {
   int xcd_map;     // 1 = xcd_row dealing of output rows (default); GOENV_XCD_MAP=0 turns it off (tuning only)
   float lut1;
   int fuse_max;    // goenv_ply_policy_sel: largest selection whose sampler runs inside the ply kernel
-  int64_t* sampled;      // moves of the two-launch form of goenv_ply_policy_sel; allocated on first use
-  int sampled_cap;
+  int64_t* sampled;      // [n] moves of the two-launch form of goenv_ply_policy_sel (allocated by goenv_create)
   hipStream_t part_stream[GOENV_MAX_PARTS];  // goenv_ply_repeat_parts; created on first use
   hipEvent_t part_event[GOENV_MAX_PARTS + 1];
   int parts_ready;
@@ -1160,10 +1158,16 @@ int goenv_create(int device, int n_boards, uint64_t seed, int64_t board_id_base,
   const char* what = "goenv_create: hipMalloc";
   if ((e = hipMalloc((void**)&c->state, (size_t)n_boards * sizeof(BoardRec))) == hipSuccess &&
       (e = hipMalloc((void**)&c->stats, STATS_ALLOC * sizeof(unsigned long long))) == hipSuccess &&
-      (e = hipMalloc((void**)&c->lut, HIST_LUT_N * sizeof(float))) == hipSuccess) {
+      (e = hipMalloc((void**)&c->lut, HIST_LUT_N * sizeof(float))) == hipSuccess &&
+      // scratch of the step path, held from the start so that no step ever allocates (a step must be
+      // capturable into a HIP graph): the sampled moves of goenv_ply_policy_sel's two-launch form and the
+      // rejected-move counter of goenv_offline_batch
+      (e = hipMalloc((void**)&c->sampled, (size_t)n_boards * sizeof(int64_t))) == hipSuccess &&
+      (e = hipMalloc((void**)&c->bad_moves, sizeof(int32_t))) == hipSuccess) {
     what = "goenv_create: initialising the boards";
     if ((e = hipMemcpy(c->lut, lut.data(), HIST_LUT_N * sizeof(float), hipMemcpyHostToDevice)) == hipSuccess &&
         (e = hipMemset(c->stats, 0, STATS_ALLOC * sizeof(unsigned long long))) == hipSuccess &&
+        (e = hipMemset(c->bad_moves, 0, sizeof(int32_t))) == hipSuccess &&
         (e = hipMemset(c->state, 0, (size_t)n_boards * sizeof(BoardRec))) == hipSuccess &&
         (e = hipEventCreate(&c->ev0)) == hipSuccess && (e = hipEventCreate(&c->ev1)) == hipSuccess) {
       GO_LAUNCH(pick_nw(c, n_boards), k_reset, n_boards, 0, c->state, n_boards, nullptr, n_boards, nullptr);
@@ -1176,6 +1180,8 @@ int goenv_create(int device, int n_boards, uint64_t seed, int64_t board_id_base,
     if (c->state) (void)hipFree(c->state);
     if (c->stats) (void)hipFree(c->stats);
     if (c->lut) (void)hipFree(c->lut);
+    if (c->sampled) (void)hipFree(c->sampled);
+    if (c->bad_moves) (void)hipFree(c->bad_moves);
     delete c;
     return fail(what, e);
   }
@@ -1216,6 +1222,7 @@ int goenv_set_waves_per_board(goenv_ctx* c, int nw) {
   return 0;
 }
 void* goenv_state_ptr(goenv_ctx* c) { return c ? (void*)c->state : nullptr; }
+int goenv_get_fuse_max(const goenv_ctx* c) { return c ? c->fuse_max : 0; }
 
 int goenv_reset(goenv_ctx* c, const int32_t* idx, int n, const int32_t* handicap, void* stream) {
   if (!c) return fail("goenv_reset: ctx is NULL");
@@ -1283,12 +1290,6 @@ static int ply_sel_impl(goenv_ctx* c, const char* who, const int32_t* idx, int f
   if (mode == 2 && count > c->fuse_max) {
     // large selections: the sampler as a launch of its own (one wave per board, all resident at once),
     // then the ply kernel on the sampled moves -- same moves, same outputs as the fused kernel
-    if (c->sampled_cap < count) {
-      if (c->sampled) HIPCHK(hipFree(c->sampled));
-      c->sampled = nullptr; c->sampled_cap = 0;
-      HIPCHK(hipMalloc((void**)&c->sampled, (size_t)c->n * sizeof(int64_t)));
-      c->sampled_cap = c->n;
-    }
     hipLaunchKernelGGL(k_sample_policy, dim3(count), dim3(64), 0, S(stream), c->state, c->n, idx, first, count, pi,
                        pi_aug, c->sampled, c->seed, c->id_base);
     HIPCHK(hipGetLastError());
@@ -1451,16 +1452,27 @@ struct StaticDev {
   unsigned char* base = nullptr;  // device address of `scratch` on this GPU
   float lut1 = 0.f;
   bool ready = false;
+  // in-use guard: the stream of the last call and an event recorded behind its kernels.  A call from
+  // ANOTHER stream while that event has not passed would race on the array and is refused.
+  hipStream_t last_stream = nullptr;
+  hipEvent_t done = nullptr;
+  bool armed = false;
 };
 static StaticDev g_static[64];
 static std::mutex g_static_mu;
 
 // Set-up, once per device, with that device current: the array's address there, then the history
 // table (the same host-evaluated exp values goenv_create uploads) copied to its first 8 KB.
-static int static_setup(int device, StaticDev** out) {
+static int static_setup(int device, hipStream_t stream, StaticDev** out) {
   std::lock_guard<std::mutex> lock(g_static_mu);
   StaticDev& d = g_static[device];
   if (!d.ready) {
+    if (stream) {   // the set-up copies synchronously: it cannot be part of a capture
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return fail("goenv_features_static: the first call on a device sets the library's array up with a synchronous "
+                    "copy; make one call before starting a stream capture");
+    }
     void* p = nullptr;
     HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
     if (!p) return fail("goenv_features_static: hipGetSymbolAddress returned NULL");
@@ -1468,6 +1480,7 @@ static int static_setup(int device, StaticDev** out) {
     for (int i = 0; i < HIST_LUT_N; ++i) lut[i] = (float)exp((double)(-i) / 10.0);
     lut[HIST_LUT_N - 1] = 0.f;
     HIPCHK(hipMemcpy(p, lut.data(), STATIC_LUT_BYTES, hipMemcpyHostToDevice));
+    HIPCHK(hipEventCreateWithFlags(&d.done, hipEventDisableTiming));
     d.base = (unsigned char*)p;
     d.lut1 = lut[1];
     d.ready = true;
@@ -1487,8 +1500,25 @@ int goenv_features_static(int device, int n, const uint8_t* color, const uint16_
   DeviceScope scope(device);
   if (scope.err != hipSuccess) return fail("goenv_features_static: selecting the device", scope.err);
   StaticDev* d = nullptr;
-  if (static_setup(device, &d)) return -1;
+  if (static_setup(device, S(stream), &d)) return -1;
   if (n == 0) return 0;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (stream) (void)hipStreamIsCapturing(S(stream), &cap);
+  const bool capturing = cap != hipStreamCaptureStatusNone;
+  if (!capturing) {   // (no event query inside a capture: a captured call is the graph owner's to order)
+    // calls on ONE stream are ordered by the stream; a call from another stream (or thread) must find the
+    // previous call's kernels finished, or it would overwrite records they are still reading
+    std::lock_guard<std::mutex> lock(g_static_mu);
+    if (d->armed && d->last_stream != S(stream)) {
+      const hipError_t q = hipEventQuery(d->done);
+      if (q == hipErrorNotReady)
+        return fail("goenv_features_static: the previous call on this GPU (another stream) is still in flight and "
+                    "all calls share one array; order the calls (one stream, or wait for the first)");
+      if (q != hipSuccess) return fail("goenv_features_static: hipEventQuery", q);
+    }
+    d->last_stream = S(stream);
+    d->armed = false;   // set again below, once this call's kernels are enqueued
+  }
   BoardRec* recs = reinterpret_cast<BoardRec*>(d->base + STATIC_LUT_BYTES);
   const float* lut = reinterpret_cast<const float*>(d->base);
   const int nw = n <= 512 ? 6 : 3;
@@ -1501,6 +1531,11 @@ int goenv_features_static(int device, int n, const uint8_t* color, const uint16_
   GO_LAUNCH(nw, k_features, n, S(stream), recs, n, (const int32_t*)nullptr, 0, n, aug_codes, lut, feat_out, legal_out,
             none, 0, d->lut1, 2, 1);   // write-through plane stores: n <= 4,096 fits the Infinity Cache
   HIPCHK(hipGetLastError());
+  if (!capturing) {   // (a captured call is replayed by the graph's owner, who orders its launches)
+    std::lock_guard<std::mutex> lock(g_static_mu);
+    HIPCHK(hipEventRecord(d->done, S(stream)));
+    d->armed = true;
+  }
   return 0;
 }
 
@@ -1545,6 +1580,13 @@ int goenv_copy(goenv_ctx* c, void* dst, const void* src, size_t bytes, void* str
   if (!c) return fail("goenv_copy: ctx is NULL");
   ON_DEVICE_OF(c);
   HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, S(stream)));
+  return 0;
+}
+
+int goenv_memset(goenv_ctx* c, void* dst, int value, size_t bytes, void* stream) {
+  if (!c) return fail("goenv_memset: ctx is NULL");
+  ON_DEVICE_OF(c);
+  if (bytes) HIPCHK(hipMemsetAsync(dst, value, bytes, S(stream)));
   return 0;
 }
 
@@ -1637,10 +1679,6 @@ int goenv_offline_batch(goenv_ctx* c, const void* block, int count, int k_future
   if (moves_offset & 1) return fail("goenv_offline_batch: moves_offset must be even");
   ON_DEVICE_OF(c);
   if (count == 0) return stage_commit(c, block, stream);
-  if (!c->bad_moves) {
-    HIPCHK(hipMalloc((void**)&c->bad_moves, sizeof(int32_t)));
-    HIPCHK(hipMemset(c->bad_moves, 0, sizeof(int32_t)));
-  }
   PlyParams P = make_params(c, 0u, nullptr, nullptr, feat_out, legal_out, nullptr, nullptr);
   P.n = count;
   P.max_ply = 0;  // a replayed record is not subject to the playout ply cap
@@ -1658,7 +1696,6 @@ int goenv_offline_bad_moves(goenv_ctx* c, int32_t* out_host, void* stream) {
   if (!c || !out_host) return fail("goenv_offline_bad_moves: NULL argument");
   ON_DEVICE_OF(c);
   *out_host = 0;
-  if (!c->bad_moves) return 0;
   HIPCHK(hipMemcpyAsync(out_host, c->bad_moves, sizeof(int32_t), hipMemcpyDeviceToHost, S(stream)));
   HIPCHK(hipStreamSynchronize(S(stream)));
   return 0;
@@ -1777,7 +1814,16 @@ int goenv_stats_host(goenv_ctx* c, int64_t* out16_host, void* stream) {
 }
 
 // RCCL, opened on first use: the library stays loadable (and every other entry point usable) on a
-// host without RCCL, and a single-GPU process never maps it.
+// host without RCCL, and a single-GPU process never maps it.  The build does not need RCCL's headers
+// either: the handful of ABI names used are declared here with the values of rccl.h (NCCL's public,
+// stable ABI: ncclDataType_t ncclInt64 = 4, ncclRedOp_t ncclSum = 0 / ncclMax = 2, ncclSuccess = 0).
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclInt64 = 4;
+constexpr ncclRedOp_t ncclSum = 0, ncclMax = 2;
 struct RcclApi {
   ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*error_string)(ncclResult_t) = nullptr;

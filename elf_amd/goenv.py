@@ -43,6 +43,7 @@ _SIGS = {
     "goenv_destroy": (C.c_int, [C.c_void_p]),
     "goenv_num_boards": (C.c_int, [C.c_void_p]),
     "goenv_set_waves_per_board": (C.c_int, [C.c_void_p, C.c_int]),
+    "goenv_get_fuse_max": (C.c_int, [C.c_void_p]),
     "goenv_state_ptr": (C.c_void_p, [C.c_void_p]),
     "goenv_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "goenv_get_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_void_p]),
@@ -70,6 +71,7 @@ _SIGS = {
                                   C.c_void_p]),
     "goenv_pointer_is_device": (C.c_int, [C.c_void_p]),
     "goenv_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "goenv_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "goenv_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "goenv_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "goenv_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -204,6 +206,9 @@ class GoEnv:
             self.close()
         except Exception:
             pass
+
+    def fuse_max(self):
+        return int(self.lib.goenv_get_fuse_max(self._h))
 
     def set_waves_per_board(self, nw):
         self._chk(self.lib.goenv_set_waves_per_board(self._h, int(nw)))

@@ -153,6 +153,10 @@ int goenv_num_boards(const goenv_ctx* ctx);
 /* Launch shape: wavefronts that share one board (1, 2, 3 or 6; 0 = chosen per launch from the
  * batch size, the default).  Results do not depend on it.  No counterpart in the reference. */
 int goenv_set_waves_per_board(goenv_ctx* ctx, int nw);
+/* goenv_get_fuse_max: the largest selection that goenv_ply_policy_sel steps in ONE launch (above
+ * it the sampler is a launch of its own; 3,072 unless GOENV_FUSE_MAX is set).  No counterpart in the
+ * reference. */
+int goenv_get_fuse_max(const goenv_ctx* ctx);
 /* device pointer to the packed records [n_boards][GOENV_REC_BYTES] */
 void* goenv_state_ptr(goenv_ctx* ctx);
 
@@ -206,8 +210,11 @@ int goenv_features(goenv_ctx* ctx, const int32_t* aug_codes, float* feat_out,
  * the process ends): n > GOENV_STATIC_MAX_BOARDS is an error.  The first call on a device looks up
  * that array's address and uploads the 8-KB history table (a synchronous copy; make one call
  * before starting a graph capture); after that the call only enqueues two kernels on `stream`.
- * All calls on one GPU share the array: calls that overlap on one GPU (different streams or
- * threads) race -- order them. */
+ * All calls on one GPU share the array, so calls must not overlap on one GPU: calls on one stream
+ * are ordered by it; a call from ANOTHER stream while the previous call's kernels are still in
+ * flight is refused with an error (it would overwrite records they read).  A first call made
+ * inside a stream capture is refused too (the set-up copy is synchronous).  Replays of a captured
+ * call are the graph owner's to order. */
 #define GOENV_STATIC_MAX_BOARDS 4096
 int goenv_features_static(int device, int n, const uint8_t* color, const uint16_t* last_placed,
                           const int32_t* scalars, const int32_t* aug_codes, float* feat_out,
@@ -276,8 +283,8 @@ int goenv_ply_sel(goenv_ctx* ctx, const int32_t* idx, int first, int count, uint
  * and the NEXT sample's planes (frame aug_codes), legal mask and sequencing record are written
  * straight into the batch arrays.  actions_out int32 [count] receives the sampled move.  One
  * launch up to 3,072 boards; above, the sampler runs as a small launch of its own in front of
- * the ply kernel (measured faster there; same moves and outputs; its int64 [n_boards] move buffer
- * is allocated by the first such call). */
+ * the ply kernel (measured faster there; same moves and outputs).  Neither form allocates: the
+ * call can be captured into a HIP graph. */
 int goenv_ply_policy_sel(goenv_ctx* ctx, const int32_t* idx, int first, int count, uint32_t flags,
                          const float* pi, const int32_t* pi_aug_codes, const int32_t* aug_codes,
                          float* feat_out, uint8_t* legal_out, const goenv_sample_out* meta,
@@ -366,6 +373,8 @@ int goenv_pointer_is_device(const void* p);
  * stream): pass the stream the context's launches use, so copies and kernels are ordered */
 int goenv_copy(goenv_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream);
 int goenv_sync(goenv_ctx* ctx, void* stream);
+/* stream-ordered byte fill of device memory on the context's device */
+int goenv_memset(goenv_ctx* ctx, void* dst, int value, size_t bytes, void* stream);
 int goenv_device_alloc(goenv_ctx* ctx, size_t bytes, void** out);
 int goenv_device_free(goenv_ctx* ctx, void* p);
 /* pinned host staging memory (for small index / action / status arrays) */

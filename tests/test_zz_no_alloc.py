@@ -112,3 +112,56 @@ def test_static_entry_point_inside_a_captured_graph(goenv):
         want_f, want_l = via_context(goenv, c2, l2, s2, None)
         assert torch.equal(feat.view(torch.int32), want_f.view(torch.int32))
         assert torch.equal(legal, want_l)
+
+
+def test_static_entry_point_refuses_overlapping_calls(goenv):
+    """All calls on one GPU share one array.  A call from another stream while the previous call's kernels
+    are still in flight is refused with an error instead of racing; once they are done it goes through."""
+    dev = torch.device("cuda", 0)
+    n = 64
+    color, lastp, scal = positions(goenv, n, 61, 60)
+    feat = torch.zeros(n, 25, 19, 19, device=dev)
+    legal = torch.zeros(n, 361, dtype=torch.uint8, device=dev)
+    a, b = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(400_000_000)                       # ~0.2 s of GPU time in front of the call on stream a
+        goenv.features_static(color, lastp, scal, feat, legal)
+        goenv.features_static(color, lastp, scal, feat, legal)   # same stream: ordered, allowed
+    with torch.cuda.stream(b):
+        with pytest.raises(goenv.GoEnvError, match="still in flight"):
+            goenv.features_static(color, lastp, scal, feat, legal)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(b):
+        goenv.features_static(color, lastp, scal, feat, legal)
+    torch.cuda.synchronize()
+    want_f, want_l = via_context(goenv, color, lastp, scal, None)
+    assert torch.equal(feat.view(torch.int32), want_f.view(torch.int32)) and torch.equal(legal, want_l)
+
+
+def test_first_call_inside_a_capture_is_refused_with_a_clear_message():
+    """The first call on a device uploads the history table with a synchronous copy.  Made inside a stream
+    capture it must fail with a message that says so (fresh process: set-up happens once per process)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import torch, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from elf_amd import goenv\n"
+        "dev = torch.device('cuda', 0)\n"
+        "c = torch.zeros(4, 361, dtype=torch.uint8, device=dev)\n"
+        "s = torch.zeros(4, 16, dtype=torch.int32, device=dev); s[:, 0] = 1; s[:, 1] = 1; s[:, 9] = -1\n"
+        "l = torch.zeros(4, 361, dtype=torch.uint8, device=dev)\n"
+        "torch.cuda.synchronize()\n"
+        "st = torch.cuda.Stream(dev)\n"
+        "g = torch.cuda.CUDAGraph()\n"
+        "try:\n"
+        "    with torch.cuda.graph(g, stream=st):\n"
+        "        goenv.features_static(c, None, s, None, l)\n"
+        "    print('NO ERROR')\n"
+        "except goenv.GoEnvError as e:\n"
+        "    print('REFUSED:', e)\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    assert "REFUSED:" in r.stdout and "before starting a stream capture" in r.stdout, (r.stdout[-400:], r.stderr[-400:])
