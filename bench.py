@@ -142,8 +142,13 @@ def main():
     backend = os.environ.get("GOENV_BENCH_BACKEND", "nccl")
     if backend == "gloo":
         local_rank %= max(1, torch.cuda.device_count())
-    if world > 1:
+    # GOENV_BENCH_FORCE_DIST=1: the process group (RCCL init with device_id, the two stats all-reduces, the
+    # barriers, the MAX over ranks of the region time, destroy) also at world size 1 -- every collective call
+    # of the N>1 path on the one GPU a test box has (tests/test_gpu_multirank.py)
+    dist_on = world > 1 or os.environ.get("GOENV_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
@@ -174,7 +179,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -199,8 +204,8 @@ def main():
         ms = env.timer_ms() / launches                # HIP events on the launch stream; average launch
         sync()
         dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if dist_on:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, ms
@@ -236,7 +241,7 @@ def main():
                    "boards_per_gpu": B, "global_boards": world * B, "ply_cap": 722,
                    "plies_per_step": T, "moves_per_step_per_gpu": B * T, "launches": launches,
                    "parallelism": "shard%d" % world,
-                   "collective_backend": backend if world > 1 else None,
+                   "collective_backend": backend if dist_on else None,
                    "preroll_plies": args.preroll, "warmup_steps_run": warm_steps, "reps": len(regions),
                    "region_ms": [round(r[0] * 1e3, 4) for r in regions], "reported": "median region"},
         "roofline": {"bound": "hbm", "kernel": "k_generate", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -262,7 +267,7 @@ def main():
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -364,6 +369,7 @@ def game_context_selfplay(B, seed, fuse, steps=1500, warm=100):
             gc.AddTensor(gid, which, info)
             keep.append(v)
     gc.Start()
+    fuse_max = gc.FuseMax()
     host = 0.0
     for i in range(warm + steps):
         if i == warm:
@@ -378,7 +384,7 @@ def game_context_selfplay(B, seed, fuse, steps=1500, warm=100):
     stats = gc.Stats()
     gc.Stop()
     return {"moves_per_s": B * steps / dt, "step_ms": dt * 1e3 / steps, "host_us_per_batch": host * 1e6 / steps,
-            "launches_per_step": (1 if B <= 3072 else 2) if fuse else 3, "steps": steps, "games_finished": stats[0],
+            "launches_per_step": (1 if B <= fuse_max else 2) if fuse else 3, "fuse_max": fuse_max, "steps": steps, "games_finished": stats[0],
             "GBps": B * ALG_BYTES_PER_BOARD / (dt / steps) / 1e9}
 
 

@@ -498,6 +498,8 @@ class GameContext {
     return d;
   }
 
+  int FuseMax() { need_env(); return goenv_get_fuse_max(env_->ctx()); }
+
   uint64_t StatsPtr() { need_env(); return reinterpret_cast<uint64_t>(goenv_stats_ptr(env_->ctx())); }
 
   std::string ShowBoard(int game_idx) {  // go/game_context.h:89-92
@@ -1619,6 +1621,7 @@ PYBIND11_MODULE(go_game, m) {
       .def("SetStream", &GameContext::SetStream)
       .def("Stats", &GameContext::Stats)
       .def("StatsPtr", &GameContext::StatsPtr)
+      .def("FuseMax", &GameContext::FuseMax)
       .def("HostTimes", &GameContext::HostTimes, py::arg("reset") = false)
       .def("SearchInfo", &GameContext::SearchInfo);
 

@@ -24,7 +24,7 @@ def shard_range(total_boards, rank, world_size):
 def reduce_stats(stats, group=None):
     """All-reduce a stats vector (int64[16]) across ranks; returns a new tensor."""
     out = stats.clone()
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return out
     mx = out[ST_MAX_LEN:ST_MAX_LEN + 1].clone()
     dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)

@@ -80,3 +80,48 @@ def test_bench_two_ranks_reduce_to_the_stats_of_one_context():
     # whole-job value = all ranks' moves / max-over-ranks time
     moves = two["config"]["global_boards"] * two["config"]["plies_per_step"] * two["steps"]
     assert abs(two["value"] - moves / (two["ms_per_step"] * 1e-3 * two["steps"])) < 1e-6 * two["value"]
+
+
+def _launch_one_rank(script_args, force_nccl):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("GOENV_BENCH_BACKEND", None)                      # default backend: nccl = RCCL
+    if force_nccl:
+        env["GOENV_BENCH_FORCE_DIST"] = "1"
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+               "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args
+    else:
+        cmd = [sys.executable] + script_args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_under_rccl_with_one_rank_equals_the_plain_run():
+    """The driver's N>1 launch line with ONE rank over RCCL (GOENV_BENCH_FORCE_DIST=1): process-group init with
+    device_id, dist.barrier(), the int64 SUM and MAX all-reduces of reduce_stats, the MAX over ranks of the
+    region time, destroy_process_group -- every collective call of the N>1 path, on the one GPU this box has.
+    Its statistics must equal the undistributed run's."""
+    common = ["--gpus", "1", "--steps", "3", "--warmup", "1", "--ring", "16", "--preroll", "430", "--reps", "1",
+              "--no-extra", "--no-cpu-baseline", "--boards", "256"]
+    script = [os.path.join(ROOT, "bench.py")] + common
+    rccl = _launch_one_rank(script, True)
+    plain = _launch_one_rank(script, False)
+    assert rccl["config"]["collective_backend"] == "nccl" and plain["config"]["collective_backend"] is None
+    assert rccl["n_gpus"] == 1 and rccl["stats"] == plain["stats"] and rccl["stats"]["games"] > 0
+    assert rccl["config"]["moves_per_step_per_gpu"] == plain["config"]["moves_per_step_per_gpu"]
+
+
+def test_selfplay_tool_under_rccl_with_one_rank():
+    """tools/df_selfplay_gpu.py (cfg 5) the same way: RCCL process group first, then the GPU; barrier, stats
+    all-reduce (SUM + MAX) and the float64 SUM / MAX of the timing vector all run over RCCL."""
+    script = [os.path.join(ROOT, "tools", "df_selfplay_gpu.py"), "--json", "--num_games", "64", "--batchsize", "64",
+              "--iters", "6", "--num_block", "2", "--dim", "32"]
+    rccl = _launch_one_rank(script, True)
+    plain = _launch_one_rank(script, False)
+    assert rccl["n_gpus"] == 1 and rccl["moves_per_s"] > 0
+    assert rccl["games_finished"] == plain["games_finished"]

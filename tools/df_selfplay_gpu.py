@@ -34,8 +34,10 @@ def main():
     backend = os.environ.get("GOENV_BENCH_BACKEND", "nccl")
     if backend == "gloo":                     # rehearsal on a box with fewer GPUs than ranks
         local_rank %= max(1, torch.cuda.device_count())
-    if world > 1:                             # before anything touches the GPU
+    dist_on = world > 1 or os.environ.get("GOENV_BENCH_FORCE_DIST") == "1"   # (=1: the collectives at world size 1)
+    if dist_on:                               # before anything touches the GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29532")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -80,7 +82,7 @@ def main():
     for _ in range(5):
         GC.Run()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     t_model[0] = 0.0
     t0 = time.perf_counter()
@@ -92,7 +94,7 @@ def main():
     dt = time.perf_counter() - t0
     stats = torch.tensor(GC.GC.Stats(), dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
     tot = torch.tensor([float(moves), dt, t_model[0]], dtype=torch.float64, device=stats.device)
-    if world > 1:
+    if dist_on:
         stats = reduce_stats(stats)
         mx = tot[1:].clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -113,7 +115,7 @@ def main():
                      100 * res["model_share"], 100 * (1 - res["model_share"]), res["env_us_per_move"],
                      res["games_finished"]), flush=True)
     GC.Stop()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
