@@ -329,18 +329,21 @@ def extra_measurements(goenv, seed):
     res["cfg3_offline_256"] = cfg3_offline()
     res["cfg5_selfplay_fp32"] = cfg5_selfplay(["--num_games", "1024", "--batchsize", "1024", "--iters", "15"])
     res["cfg5_selfplay_bf16"] = cfg5_selfplay(["--num_games", "2048", "--batchsize", "2048", "--iters", "15", "--bf16"])
-    env = goenv.GoEnv(1024, seed=seed, max_ply=722)
-    nm = env.new(torch.int32)
-    env.playout(None, nm)
-    torch.cuda.synchronize()
-    env.reset()
-    env.timer_begin()
-    env.playout(None, nm)
-    env.timer_end()
-    ms = env.timer_ms()
-    res["persistent_playout_1024"] = {"ms": ms, "moves": int(nm.sum().item()),
-                                      "moves_per_s": float(nm.sum().item()) / (ms * 1e-3)}
-    env.close()
+    # the rules-only step kernel (k_playout: whole games with the board in LDS/registers, no planes) -- the
+    # LDS/VALU-bound half of the path; its counters against gfx950 peaks: profiles/r03_playout.md
+    for B in (1024, 8192, 65536):
+        env = goenv.GoEnv(B, seed=seed, max_ply=722)
+        nm = env.new(torch.int32)
+        env.playout(None, nm)
+        torch.cuda.synchronize()
+        env.reset()
+        env.timer_begin()
+        env.playout(None, nm)
+        env.timer_end()
+        ms = env.timer_ms()
+        res["persistent_playout_%d" % B] = {"ms": ms, "moves": int(nm.sum().item()),
+                                            "moves_per_s": float(nm.sum().item()) / (ms * 1e-3)}
+        env.close()
     return res
 
 
