@@ -217,7 +217,6 @@ class GameContext {
     mcts_ = opt_.use_mcts && !offline_;  // GoGame::Init builds an MCTSGoAI only for online / selfplay, go/game.cc:38-41
     if (mcts_) {
       const TSOptions& ts = co_.mcts_options;
-      if (ts.persistent_tree) throw std::range_error("mcts_options.persistent_tree is not supported: every move starts a fresh tree");
       if (ts.num_threads < 1 || ts.num_rollout_per_thread < 1)
         throw std::range_error("mcts_options: num_threads and num_rollout_per_thread must be >= 1");
       if (ts.pick_method != "most_visited" && ts.pick_method != "strongest_prior" && ts.pick_method != "uniform_random")
@@ -342,7 +341,7 @@ class GameContext {
     const int npt = offline_ ? std::max(1, opt_.num_games_per_thread) : 1;
     if (offline_ && corpus_.size() == 0) throw std::range_error("Start(): offline mode needs a readable list_filename");
     // tree search: every game owns a pool of node positions behind the games' own boards
-    const int pool = mcts_ ? co_.mcts_options.num_threads * co_.mcts_options.num_rollout_per_thread : 0;
+    const int pool = mcts_ ? TreeSearch::pool_slots(co_.mcts_options) : 0;
     const long long n_boards = (long long)co_.num_games * (mcts_ ? 1 + pool : npt);
     if (n_boards > (1ll << 30)) throw std::range_error("Start(): num_games x node pool exceeds 2^30 boards");
     env_.reset(new DeviceEnv(opt_.gpu, (int)n_boards, opt_.seed ? opt_.seed : 1, opt_.board_id_base, opt_.komi,
@@ -549,6 +548,7 @@ class GameContext {
     int ply = 1;        // host mirror of _ply for play modes that keep host sequencing
     std::vector<LeafRequest> requests;  // tree search: the outstanding leaf of every search thread
     int last_move = -3;                 // tree search: the move the last finished search played
+    std::vector<int> moves_since;       // tree search: moves accepted on the game's board since the last search began
     long moves_played = 0;
     // general path (histories, several groups per sample)
     std::vector<HistEntry> hist;        // ring of ContextOptions.T entries
@@ -645,7 +645,8 @@ class GameContext {
       ld.prefetch();      // 76,800 replays do not fit the caches: ask for this one's lines now, use them in Wait
     }
     if (mcts_ && gs.phase == 1) {  // MCTSAI_T::Act: a fresh tree rooted at the game's position
-      searches_[g]->begin(g);
+      searches_[g]->begin(g, gs.moves_since);   // (persistent_tree: advanced along the moves since the last search)
+      gs.moves_since.clear();
       pump(g);
       return;
     }
@@ -712,8 +713,14 @@ class GameContext {
         GameSlot& gs = games_[games[i]];
         gs.last_move = (int)acts[i];
         gs.moves_played += 1;
-        if (st[i] == 1) gs.ply += 1;
-        else gs.ply = 1;  // illegal / ended: the board was reset
+        if (st[i] == 1) {
+          gs.ply += 1;
+          gs.moves_since.push_back((int)acts[i]);
+        } else {          // illegal / ended: the board was reset, nothing of the tree applies (MCTSAI_T::GameEnd)
+          gs.ply = 1;
+          gs.moves_since.clear();
+          searches_[games[i]]->reset();
+        }
         if (has_human) gs.phase = 0;
         produce_sample(games[i]);
       }
@@ -1062,12 +1069,19 @@ class GameContext {
     if (online) {  // host sequencing needs the legality of each move
       std::vector<int32_t> st(n);
       env_->d2h(st.data(), d_status, (size_t)n * 4);
+      // a persistent search tree follows the human's moves too (moves_since, elf/mcts.h:105-110)
+      const bool track = mcts_ && co_.mcts_options.persistent_tree;
+      std::vector<int64_t> played(track ? n : 0);
+      if (track) env_->d2h(played.data(), d_a, (size_t)n * 8);
       env_->sync();
       const bool has_human = group_of("human_actor") >= 0 && groups_[group_of("human_actor")].name == "human_actor";
       for (int r = 0; r < n; ++r) {
         GameSlot& gs = games_[c.games[r] / tick_];
         if (gs.phase == 0) {
-          if (st[r] == 1) { gs.ply += 1; gs.phase = 1; }
+          if (st[r] == 1) {
+            gs.ply += 1; gs.phase = 1;
+            if (track) gs.moves_since.push_back((int)played[r]);
+          }
         } else {
           if (st[r] == 1) gs.ply += 1;
           else gs.ply = 1;  // reset
@@ -1628,7 +1642,12 @@ PYBIND11_MODULE(go_game, m) {
   // the host-side tree search by itself (CPU tests drive it against a board engine of their own)
   py::class_<TreeSearch>(m, "TreeSearch")
       .def(py::init<const TSOptions&, int, int>())
-      .def("begin", &TreeSearch::begin)
+      .def("begin", &TreeSearch::begin, py::arg("root_slot"), py::arg("moves_since") = std::vector<int>())
+      .def("reset", &TreeSearch::reset)
+      .def_static("pool_slots", &TreeSearch::pool_slots)
+      .def("child_edges", &TreeSearch::child_edges)
+      .def("root_count", &TreeSearch::root_count)
+      .def("free_slots", &TreeSearch::free_slots)
       .def("advance", [](TreeSearch& ts) {
         std::vector<LeafRequest> rq;
         ts.advance(&rq);

