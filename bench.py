@@ -327,6 +327,7 @@ def extra_measurements(goenv, seed):
             res["game_context_selfplay_%d" % B]["moves_per_s"] / res["launch_per_ply_%d" % B]["moves_per_s"])
         res["game_context_selfplay_%d" % B]["unfused_round1_path"] = game_context_selfplay(B, seed, False, steps=300)
     res["cfg3_offline_256"] = cfg3_offline()
+    res["mcts_256x16x100"] = mcts_search()
     res["cfg5_selfplay_fp32"] = cfg5_selfplay(["--num_games", "1024", "--batchsize", "1024", "--iters", "15"])
     res["cfg5_selfplay_bf16"] = cfg5_selfplay(["--num_games", "2048", "--batchsize", "2048", "--iters", "15", "--bf16"])
     # the rules-only step kernel (k_playout: whole games with the board in LDS/registers, no planes) -- the
@@ -399,6 +400,20 @@ def cfg5_selfplay(flags):
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "df_selfplay_gpu.py"), "--json"] + flags,
                            capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(lines[-1]) if lines else {"error": r.stderr[-300:]}
+    except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+        return {"error": repr(e)}
+
+
+def mcts_search():
+    """tree search behind the GameContext, 256 games x 16 search threads x 100 rollouts, leaf
+    evaluations per second with a reply that costs nothing (tools/time_mcts.py in a child process; beside it
+    the UNMODIFIED reference module, 16 games x 16 threads = 256 OS threads on this host's cores)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "time_mcts.py"), "--evals", "150000"],
+                           capture_output=True, text=True, timeout=400)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         return json.loads(lines[-1]) if lines else {"error": r.stderr[-300:]}
     except (subprocess.TimeoutExpired, OSError, ValueError) as e:

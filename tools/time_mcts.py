@@ -87,9 +87,13 @@ def run_ours(args):
     n, dt, batches = loop(gc, args.evals, args.evals // 10)
     torch.cuda.synchronize()
     moves = sum(gc.SearchInfo(g)["moves_played"] for g in range(args.games))
+    ht = gc.HostTimes()
     gc.Stop()
     return {"games": args.games, "threads": args.threads, "rollouts_per_thread": args.rollouts, "evaluations": n,
-            "seconds": dt, "evaluations_per_s": n / dt, "rows_per_batch": n / max(1, batches), "moves_played": moves}
+            "seconds": dt, "evaluations_per_s": n / dt, "rows_per_batch": n / max(1, batches), "moves_played": moves,
+            "us_per_batch": dt / max(1, batches) * 1e6,
+            "host_us_per_batch": (ht["wait_us"] + ht["steps_us"]) / max(1, ht["waits"]),
+            "host_threads": int(os.environ.get("GOENV_HOST_THREADS", "0")) or min(8, os.cpu_count() or 1)}
 
 
 def run_reference_child(args):
