@@ -212,7 +212,17 @@ __device__ __forceinline__ void load_record(const BoardRec* rec, BoardLds<NW>& L
   load_masks(rec, m);
   uint4* stage = reinterpret_cast<uint4*>(L.lib);
   const uint4* src = reinterpret_cast<const uint4*>(rec);
+#ifdef GOENV_REC_LD_SC1
+  // probe (tools/ablate.py): the record read past the XCD's L2 (agent-scope loads, `sc1`)
+  for (int i = g.tid; i < LABS_VEC; i += 64 * NW) {
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(src + i);
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stage[i] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+  }
+#else
   for (int i = g.tid; i < LABS_VEC; i += 64 * NW) stage[i] = src[i];
+#endif
   fill_rim(L, g.tid);
   WSYNC();
   const uint16_t* raw = reinterpret_cast<const uint16_t*>(L.lib);
@@ -331,8 +341,14 @@ __device__ __forceinline__ void store_board(BoardRec* rec, const Geo<NW>& g, con
   GO_UNROLL
   for (int k = 0; k < K; ++k) {
     if (g.p[k] < NPTS) {
+#ifdef GOENV_REC_ST_SC1
+      // probe (tools/ablate.py): the record written through the XCD's L2 (agent-scope stores, `sc1`)
+      __hip_atomic_store(&rec->lab[g.p[k]], (uint16_t)lab[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&rec->lastp[g.p[k]], (uint16_t)lastp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
       rec->lab[g.p[k]] = (uint16_t)lab[k];
       rec->lastp[g.p[k]] = (uint16_t)lastp[k];
+#endif
     }
   }
   // this wave's mask words: lane k writes the legal word, lane K + k the candidate word

@@ -25,7 +25,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     print("%-28s %6d boards  %.2f us" % (os.path.basename(sys.argv[2]), B, env.timer_ms() * 2), flush=True)
     sys.exit(0)
 
-for B in (1024,):
+for B in [int(x) for x in os.environ.get('ABLATE_BOARDS', '1024').split(',')]:
     for name in ["libgoenv.so"] + sorted(f for f in os.listdir(os.path.join(ROOT, "elf_amd")) if f.startswith("libgoenv_ab_")):
         subprocess.run([sys.executable, os.path.abspath(__file__), "--one", os.path.join(ROOT, "elf_amd", name), str(B)],
                        timeout=120)
