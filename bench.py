@@ -99,7 +99,7 @@ def measured_traffic(boards, plies_per_launch):
     MI355X_MICROARCH.md prescribes (tools/profile_round.sh -> profiles/rNN_pmc.json), scaled to this
     run's plies per launch (the kernel writes the same bytes for every ply).  (None, None) when no
     pass exists for this batch size."""
-    for name in ("r02_pmc.json", "r01_pmc.json"):
+    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
