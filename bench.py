@@ -326,6 +326,9 @@ def extra_measurements(goenv, seed):
         res["game_context_selfplay_%d" % B]["vs_launch_per_ply"] = (
             res["game_context_selfplay_%d" % B]["moves_per_s"] / res["launch_per_ply_%d" % B]["moves_per_s"])
         res["game_context_selfplay_%d" % B]["unfused_round1_path"] = game_context_selfplay(B, seed, False, steps=300)
+        # optional mode, never the headline: tensors zero-filled once, the 11 constant planes (44 % of the bytes) never
+        # written again (GameOptions.preset_zero_planes); planes stay bit-identical (tests/test_gpu_soak.py)
+        res["game_context_selfplay_%d" % B]["preset_zero_planes"] = game_context_selfplay(B, seed, True, preset=True)
     res["cfg3_offline_256"] = cfg3_offline()
     res["mcts_256x16x100"] = mcts_search()
     res["cfg5_selfplay_fp32"] = cfg5_selfplay(["--num_games", "1024", "--batchsize", "1024", "--iters", "15"])
@@ -348,7 +351,7 @@ def extra_measurements(goenv, seed):
     return res
 
 
-def game_context_selfplay(B, seed, fuse, steps=1500, warm=100):
+def game_context_selfplay(B, seed, fuse, steps=1500, warm=100, preset=False):
     """GameContext in selfplay mode (elf_amd.go_game, the drop-in for the reference's pybind module):
     B games, ONE collector of batch B, device tensors `s` + `legal` in, `pi` + `V` out; the reply is a
     constant uniform pi already on the device (no model), so the number is the environment's own
@@ -359,6 +362,7 @@ def game_context_selfplay(B, seed, fuse, steps=1500, warm=100):
     co.num_games = B
     opt = go.GameOptions()
     opt.mode, opt.seed, opt.ply_cap, opt.end_on_two_passes, opt.fuse_selfplay = "selfplay", seed, 722, True, fuse
+    opt.preset_zero_planes = preset
     gc = go.GameContext(co, opt)
     gs = gc.CreateGroupStat()
     gs.name = "actor"
@@ -368,7 +372,7 @@ def game_context_selfplay(B, seed, fuse, steps=1500, warm=100):
     for which, keys in (("input", ("s", "legal")), ("reply", ("pi", "V"))):
         for key in keys:
             info = gc.GetTensorSpec(gid, key, 1)
-            v = torch.ones(*info.sz, dtype=tt[info.type], device="cuda:0")
+            v = (torch.zeros if preset and key == "s" else torch.ones)(*info.sz, dtype=tt[info.type], device="cuda:0")
             info.p, info.byte_size = v.data_ptr(), v.numel() * v.element_size()
             gc.AddTensor(gid, which, info)
             keep.append(v)
@@ -389,7 +393,8 @@ def game_context_selfplay(B, seed, fuse, steps=1500, warm=100):
     gc.Stop()
     return {"moves_per_s": B * steps / dt, "step_ms": dt * 1e3 / steps, "host_us_per_batch": host * 1e6 / steps,
             "launches_per_step": (1 if B <= fuse_max else 2) if fuse else 3, "fuse_max": fuse_max, "steps": steps, "games_finished": stats[0],
-            "GBps": B * ALG_BYTES_PER_BOARD / (dt / steps) / 1e9}
+            "GBps": B * (ALG_BYTES_PER_BOARD - (11 * 361 * 4 if preset else 0)) / (dt / steps) / 1e9,
+            "plane_bytes_written_per_board": ALG_BYTES_PLANES - (11 * 361 * 4 if preset else 0)}
 
 
 def cfg5_selfplay(flags):

@@ -86,6 +86,8 @@ struct GameOptions {
                                    // (the reference's Go loop never calls AIComm::Restart there)
   int64_t board_id_base = 0;       // global id of game 0 (rank * num_games in a sharded job): the on-device
                                    // RNG is keyed by the global id, so ranks play different games
+  bool preset_zero_planes = false; // the caller's `s` tensors were zero-filled once and stay the caller's: the 11 constant
+                                   // planes (12, 13, 16..24) are never written (goenv_set_constant_planes_preset)
   bool fuse_selfplay = true;       // selfplay with device tensors: Steps() = ONE launch that also writes the
                                    // games' next samples (false: Wait() extracts them, as in round 1)
 };
@@ -347,6 +349,16 @@ class GameContext {
     env_.reset(new DeviceEnv(opt_.gpu, (int)n_boards, opt_.seed ? opt_.seed : 1, opt_.board_id_base, opt_.komi,
                              opt_.ply_cap, offline_ ? 1 : 0));
     env_->set_stream(stream_);
+    if (opt_.preset_zero_planes) {
+      // device tensors only: the planes of a host tensor travel through staging buffers of this context,
+      // whose constant planes nobody would have cleared
+      for (const auto& c : collectors_)
+        for (const auto& kv : c->input)
+          if (kv.first == "s" && !kv.second.device)
+            throw std::range_error("GameOptions.preset_zero_planes needs the \"s\" tensors in device memory");
+      if (co_.T > 1) throw std::range_error("GameOptions.preset_zero_planes is not supported with history length T > 1");
+      chk(goenv_set_constant_planes_preset(env_->ctx(), 1), "goenv_set_constant_planes_preset");
+    }
     games_.clear();
     games_.resize(co_.num_games);
     searches_.clear();
@@ -1593,6 +1605,7 @@ PYBIND11_MODULE(go_game, m) {
       .def_readwrite("end_on_two_passes", &GameOptions::end_on_two_passes)
       .def_readwrite("signal_restart", &GameOptions::signal_restart)
       .def_readwrite("board_id_base", &GameOptions::board_id_base)
+      .def_readwrite("preset_zero_planes", &GameOptions::preset_zero_planes)
       .def_readwrite("fuse_selfplay", &GameOptions::fuse_selfplay);
 
   py::class_<EntryInfo>(m, "EntryInfo")

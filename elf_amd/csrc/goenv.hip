@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64 * NW) void k_ply(PlyParams P) {
   const int pre_ply = s.ply + 1;  // every accepted move, pass included, advances the ply by one
   if (P.feat) {
     history_preload(g, lastp, pre_ply, P.lut, hv_pre);
-    if (P.zero_first & 1) {
+    if ((P.zero_first & 5) == 1) {
       if (P.zero_first & 2) zero_planes<NW, true>(g, P.feat + (size_t)b * GOENV_FEAT_FLOATS);
       else zero_planes<NW, false>(g, P.feat + (size_t)b * GOENV_FEAT_FLOATS);
     }
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(64 * NW) void k_features(BoardRec* state, int n_tot
   float hv_pre[K];
   if (feat) {
     history_preload(g, lastp, s.ply, lut, hv_pre);
-    if (zero_first & 1) {
+    if ((zero_first & 5) == 1) {
       if (zero_first & 2) zero_planes<NW, true>(g, feat + (size_t)b * GOENV_FEAT_FLOATS);
       else zero_planes<NW, false>(g, feat + (size_t)b * GOENV_FEAT_FLOATS);
     }
@@ -715,8 +715,12 @@ __global__ __launch_bounds__(64 * NW) void k_generate(PlyParams P, int n_plies, 
     STAMP(11);
     if (P.feat) {
       const int aug = P.aug ? (P.aug[b] & 7) : 0;
-      write_features<NW, true, false>(L, g, lab, lastp, s, aug, P.lut, P.feat + row * GOENV_FEAT_FLOATS, hv_none, -1,
-                                      P.lut1, P.stamps);
+      if (P.zero_first & 4)   // constant planes preset by the caller (goenv_set_constant_planes_preset)
+        write_features<NW, false, false>(L, g, lab, lastp, s, aug, P.lut, P.feat + row * GOENV_FEAT_FLOATS, hv_none, -1,
+                                         P.lut1, P.stamps);
+      else
+        write_features<NW, true, false>(L, g, lab, lastp, s, aug, P.lut, P.feat + row * GOENV_FEAT_FLOATS, hv_none, -1,
+                                        P.lut1, P.stamps);
     }
     STAMP(12);
   }
@@ -866,8 +870,12 @@ __global__ __launch_bounds__(64 * NW) void k_offline(PlyParams P, const int32_t*
   }
   if (P.feat) {
     float* out = P.feat + (size_t)b * GOENV_FEAT_FLOATS;
-    if (P.zero_first & 2) write_features<NW, true, true>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1);
-    else write_features<NW, true, false>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1);
+    switch (P.zero_first & 6) {
+      case 0: write_features<NW, true, false>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
+      case 2: write_features<NW, true, true>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
+      case 4: write_features<NW, false, false>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
+      default: write_features<NW, false, true>(L, g, lab, lastp, s, aug, P.lut, out, hv_pre, pre_ply, P.lut1); break;
+    }
   }
   if (cnt > 0 && cnt == n) move_masks(L, g, lab, s, s.next, o);   // (a rejected move left `o` at the position's masks)
   if (dirty) store_board(rec, g, lab, lastp, o, s);
@@ -1035,6 +1043,7 @@ struct goenv_ctx {
   int stage_busy[GOENV_STAGE_SLOTS];   // an event has been recorded after the slot's last reader
   int stage_next;
   int32_t* bad_moves;                  // device counter of goenv_offline_batch rows that hit a rejected move
+  int planes_preset;                   // goenv_set_constant_planes_preset
 };
 
 // The standalone feature kernel has no rules phase that staggers its waves' stores: mid-size
@@ -1052,6 +1061,8 @@ static int pick_nw_features(const goenv_ctx* c, int count) {
 // whole output fits the caches (no end-of-kernel write-back of tens of MB: 13.2 -> 12.1 us at
 // 1,024 boards) and costs 1.5x on an HBM-sized stream, so it is used for launches of up to 4,096 boards.
 static int pick_zero_first(const goenv_ctx* c, int count) {
+  // bit 2 (+ bit 0: write_features then skips them too): the caller keeps the 11 constant planes zero itself
+  if (c->planes_preset) return ((c->zero_first >= 0 ? c->zero_first : (count <= 4096 ? 2 : 0)) & 2) | 5;
   if (c->zero_first >= 0) return c->zero_first;
   // tools/tune_waves.py under GOENV_ZERO_FIRST=0 / 2: write-through wins up to 6,144 boards (16.5 -> 14.6 us at
   // 1,536, 18.8 -> 17.0 at 2,048, 31.5 -> 30.5 at 4,096, 42.9 -> 42.4 at 6,144) and loses badly once a ply's planes
@@ -1223,6 +1234,12 @@ int goenv_set_waves_per_board(goenv_ctx* c, int nw) {
 }
 void* goenv_state_ptr(goenv_ctx* c) { return c ? (void*)c->state : nullptr; }
 int goenv_get_fuse_max(const goenv_ctx* c) { return c ? c->fuse_max : 0; }
+
+int goenv_set_constant_planes_preset(goenv_ctx* c, int on) {
+  if (!c) return fail("goenv_set_constant_planes_preset: ctx is NULL");
+  c->planes_preset = on ? 1 : 0;
+  return 0;
+}
 
 int goenv_reset(goenv_ctx* c, const int32_t* idx, int n, const int32_t* handicap, void* stream) {
   if (!c) return fail("goenv_reset: ctx is NULL");

@@ -21,15 +21,17 @@ _TORCH = {"float": torch.float32, "int64_t": torch.int64, "int32_t": torch.int32
 _NUMPY = {"float": "f4", "int64_t": "i8", "int32_t": "i4", "char": "i1", "unsigned char": "u1"}
 
 
-def _allocate(info, device, use_numpy):
+def _allocate(info, device, use_numpy, zero=False):
     """Storage for one EntryInfo; fills in its pointer and byte size.  Filled with ones like the
-    reference does (elf/utils_elf.py:58,63) so that untouched entries are visible in debugging."""
+    reference does (elf/utils_elf.py:58,63) so that untouched entries are visible in debugging;
+    `zero`: filled with zeros instead (the planes tensor of a context that never writes the constant
+    planes, GameOptions.preset_zero_planes)."""
     shape = tuple(info.sz)
     if use_numpy:
-        arr = np.ones(shape, dtype=_NUMPY[info.type])
+        arr = (np.zeros if zero else np.ones)(shape, dtype=_NUMPY[info.type])
         info.p, info.byte_size = arr.ctypes.data, arr.nbytes
         return arr
-    t = torch.ones(shape, dtype=_TORCH[info.type], device=device or "cpu")
+    t = (torch.zeros if zero else torch.ones)(shape, dtype=_TORCH[info.type], device=device or "cpu")
     if device is None and torch.cuda.is_available():
         t = t.pin_memory()
     info.p, info.byte_size = t.data_ptr(), t.numel() * t.element_size()
@@ -54,13 +56,13 @@ class Batch:
         self.batch = tensors
 
     @classmethod
-    def load(cls, GC, input_reply, desc, group_id, device=None, use_numpy=False):
+    def load(cls, GC, input_reply, desc, group_id, device=None, use_numpy=False, zero_planes=False):
         """Allocate every key of a descriptor half ({"T":..., "keys":...}) and register it."""
         self = cls()
         self.GC, self.dims = GC, {}
         for key in desc["keys"]:
             info = _spec(GC, group_id, key, desc["T"])
-            self.batch[info.key] = _allocate(info, device, use_numpy)
+            self.batch[info.key] = _allocate(info, device, use_numpy, zero=zero_planes and info.key == "s")
             self.dims[info.key] = info
             GC.AddTensor(group_id, input_reply, info)
         return self
@@ -128,7 +130,7 @@ class Batch:
 class GCWrapper:
     """Collectors, batches and the Wait -> callback -> Steps loop (elf/utils_elf.py:214-402)."""
 
-    def __init__(self, GC, co, descriptions, use_numpy=False, gpu=None, params=None):
+    def __init__(self, GC, co, descriptions, use_numpy=False, gpu=None, params=None, zero_planes=False):
         self.GC = GC
         self.gpu = gpu
         self.device = None if gpu is None else torch.device("cuda", gpu)
@@ -151,7 +153,8 @@ class GCWrapper:
             self.name2idx[name] = []
             for _ in range(per_desc):
                 gid = GC.AddCollectors(d["batchsize"], exclusive_id, d.get("timeout_usec", 0), gstat)
-                inp = Batch.load(GC, "input", d["input"], gid, device=self.device, use_numpy=use_numpy)
+                inp = Batch.load(GC, "input", d["input"], gid, device=self.device, use_numpy=use_numpy,
+                                 zero_planes=zero_planes)
                 inp.batchsize = d["batchsize"]
                 self.inputs.append(inp)
                 rep = None

@@ -50,6 +50,8 @@ def add_arguments(parser=None):
     p.add_argument("--ply_cap", type=int, default=0)
     p.add_argument("--end_on_two_passes", action="store_true")
     p.add_argument("--signal_restart", action="store_true")
+    p.add_argument("--preset_zero_planes", action="store_true",
+                   help="the batch tensors are zero-filled once (they are, by GCWrapper): never write the 11 constant planes")
     p.add_argument("--legal_mask", action="store_true", help="add the `legal` key to the actor inputs")
     p.add_argument("--board_id_base", type=int, default=0,
                    help="global id of game 0 (rank * num_games in a sharded job): keys the on-device RNG")
@@ -111,6 +113,7 @@ def initialize(args):
     opt.ply_cap = args.ply_cap
     opt.end_on_two_passes = args.end_on_two_passes
     opt.signal_restart = args.signal_restart
+    opt.preset_zero_planes = getattr(args, "preset_zero_planes", False)
     opt.board_id_base = args.board_id_base
     if getattr(args, "verbose", False):               # the reference prints these unconditionally (go/game.py:46,59-62)
         co.print()
@@ -120,4 +123,5 @@ def initialize(args):
         print("Version: ", GC.Version())
         print("Num Actions: ", params["num_action"])
     params.update(dict(num_group=1 if args.actor_only else 2, T=args.T))
-    return GCWrapper(GC, co, descriptors(args), gpu=args.gpu, use_numpy=False, params=params)
+    return GCWrapper(GC, co, descriptors(args), gpu=args.gpu, use_numpy=False, params=params,
+                     zero_planes=getattr(args, "preset_zero_planes", False))

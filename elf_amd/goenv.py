@@ -44,6 +44,7 @@ _SIGS = {
     "goenv_num_boards": (C.c_int, [C.c_void_p]),
     "goenv_set_waves_per_board": (C.c_int, [C.c_void_p, C.c_int]),
     "goenv_get_fuse_max": (C.c_int, [C.c_void_p]),
+    "goenv_set_constant_planes_preset": (C.c_int, [C.c_void_p, C.c_int]),
     "goenv_state_ptr": (C.c_void_p, [C.c_void_p]),
     "goenv_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "goenv_get_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_void_p]),
@@ -209,6 +210,10 @@ class GoEnv:
 
     def fuse_max(self):
         return int(self.lib.goenv_get_fuse_max(self._h))
+
+    def set_constant_planes_preset(self, on=True):
+        """The caller keeps planes 12, 13, 16..24 of its (zero-filled) tensors: no kernel writes them."""
+        self._chk(self.lib.goenv_set_constant_planes_preset(self._h, 1 if on else 0))
 
     def set_waves_per_board(self, nw):
         self._chk(self.lib.goenv_set_waves_per_board(self._h, int(nw)))

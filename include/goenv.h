@@ -157,6 +157,15 @@ int goenv_set_waves_per_board(goenv_ctx* ctx, int nw);
  * it the sampler is a launch of its own; 3,072 unless GOENV_FUSE_MAX is set).  No counterpart in the
  * reference. */
 int goenv_get_fuse_max(const goenv_ctx* ctx);
+/* goenv_set_constant_planes_preset(ctx, 1): from now on no entry point of this context writes the 11
+ * planes that BoardFeature::Extract never fills (12, 13, 16..24: go/board_feature.h:13-28,
+ * go/board_feature.cc:178-179 -- constant zeros, 44 % of a sample's bytes).  For callers whose batch
+ * tensors are long-lived and were zero-filled once (ELF allocates its batch tensors once, at
+ * start-up, elf/utils_elf.py:52-99): the planes stay bit-identical to Extract's output while a ply
+ * writes 20,216 B of planes per board instead of 36,100.  The caller owns that invariant: a tensor
+ * that held anything else in those planes keeps it.  Off by default; no counterpart in the
+ * reference (its Extract clears the whole vector on every call). */
+int goenv_set_constant_planes_preset(goenv_ctx* ctx, int on);
 /* device pointer to the packed records [n_boards][GOENV_REC_BYTES] */
 void* goenv_state_ptr(goenv_ctx* ctx);
 

@@ -97,11 +97,14 @@ def test_errors_are_python_exceptions(go):
         gc.SearchInfo(0)
     co = go.ContextOptions()
     co.num_games = 2
-    co.mcts_options.persistent_tree = True                          # the one tree-search option not carried over
+    co.mcts_options.pick_method = "best_guess"                      # elf/tree_search.h:266-269
     opt = go.GameOptions()
     opt.mode, opt.seed, opt.use_mcts = "selfplay", 3, True
-    with pytest.raises(Exception, match="persistent_tree"):
+    with pytest.raises(Exception, match="Pick method unknown"):
         go.GameContext(co, opt)
+    co.mcts_options.pick_method = "most_visited"
+    co.mcts_options.persistent_tree = True                          # accepted since round 3
+    go.GameContext(co, opt)
 
 
 def test_sgf_reader_matches_the_reference_on_the_corpus(go):

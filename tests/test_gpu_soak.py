@@ -169,3 +169,57 @@ def test_generator_across_game_ends_against_oracle(boards, cap, plies, launches)
             account(o)
     assert env.stats() == want
     env.close()
+
+
+CONSTANT_PLANES = [12, 13] + list(range(16, 25))
+
+
+@pytest.mark.parametrize("boards,plies", [(1024, 60), (4200, 8)])
+def test_constant_planes_preset_keeps_every_float(boards, plies):
+    """goenv_set_constant_planes_preset: the caller zero-fills its tensors ONCE and no kernel writes planes
+    12, 13, 16..24 again.  Every float of every board on every ply must still equal BoardFeature::Extract's
+    (oracle), through k_ply, k_features and the generator; a sentinel written into a constant plane must
+    survive (nothing writes there)."""
+    from elf_amd import goenv
+    goenv.load_library()
+    env = goenv.GoEnv(boards, seed=33, max_ply=722)
+    env.set_constant_planes_preset(True)
+    feat = env.new(torch.float32, 25, 19, 19)            # zero-filled once, never again
+    feat2 = env.new(torch.float32, 25, 19, 19)
+    legal = env.new(torch.uint8, 361)
+    acts = env.new(torch.int32)
+    oracles = [OracleBoard() for _ in range(boards)]
+    flags = goenv.F_RANDOM_POLICY | goenv.F_AUTO_RESTART
+    bad = 0
+    for t in range(plies):
+        env.ply(flags, feat_out=feat, legal_out=legal, actions_out=acts)
+        env.features(feat2, None, None)
+        assert torch.equal(feat.view(torch.int32), feat2.view(torch.int32)), "k_features differs from k_ply at ply %d" % t
+        f = feat.cpu().numpy().reshape(boards, -1)
+        for b, a in enumerate(acts.cpu().tolist()):
+            o = oracles[b]
+            assert o.forward(a)[0]
+            if not np.array_equal(f[b], o.extract(0)):
+                bad += 1
+    assert bad == 0, "%d of %d board-plies differ from the oracle" % (bad, boards * plies)
+    feat[:, 20, 3, 3] = 7.0                               # a constant plane: nobody writes it any more
+    env.ply(flags, feat_out=feat, legal_out=legal, actions_out=acts)
+    assert bool((feat[:, 20, 3, 3] == 7.0).all()) and bool((feat[:, CONSTANT_PLANES].sum() == 7.0 * boards).item())
+    # the generator: rings zero-filled once
+    T = 4
+    ring = torch.zeros(T, boards, 25, 19, 19, device=env.device)
+    moves = torch.empty(T, boards, dtype=torch.int32, device=env.device)
+    for b, a in enumerate(acts.cpu().tolist()):
+        assert oracles[b].forward(a)[0]
+    env.generate(T, ring, None, moves)
+    mv = moves.cpu().numpy()
+    games = np.zeros(boards, np.int64)
+    for t in range(T):
+        f = ring[t].cpu().numpy().reshape(boards, -1)
+        for b in range(0, boards, 7):
+            o = oracles[b]
+            if o.is_game_end() or o.canonical()["scalars"][0] > 722:
+                o = oracles[b] = OracleBoard()
+            assert o.forward(int(mv[t, b]))[0]
+            assert np.array_equal(f[b], o.extract(0)), (t, b)
+    env.close()
