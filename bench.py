@@ -90,7 +90,22 @@ def cpu_baseline(budget_sec=12.0):
                   "job's CPU share (%d of the host's %d logical CPUs), %d plies in %.1f s (budget %.0f s)"
                   % (threads, host, plies, sec, budget_sec),
         "value_without_features": plies_nf / sec_nf,
+        # ELF's own structure for the same job (not the favourable thread pool above): the unmodified reference
+        # go_game module in selfplay mode, ONE OS THREAD PER GAME, Extract + collector hand-shake + forward per move,
+        # numpy batch buffers, a reply that costs nothing (tools/time_selfplay_ref.py)
+        "elf_thread_per_game": elf_selfplay_reference(),
     }
+
+
+def elf_selfplay_reference():
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "time_selfplay_ref.py"), "--games", "1024",
+                            "--batch", "1024", "--batches", "60"], capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(lines[-1]) if lines else {"error": r.stderr[-300:]}
+    except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+        return {"error": repr(e)}
 
 
 def measured_traffic(boards, plies_per_launch):
