@@ -411,7 +411,14 @@ class GameContext {
   void Stop() {
     if (!started_) return;
     if (env_) {
-      try { env_->sync(); } catch (...) {}
+      try {
+        env_->sync();
+        if (offline_) {
+          int32_t bad = 0;
+          if (goenv_offline_bad_moves(env_->ctx(), &bad, env_->stream()) == 0 && bad > 0)
+            std::cout << "[go_game] WARNING: the device rejected " << bad << " replayed record move(s) that the host took for legal" << std::endl;
+        }
+      } catch (...) {}
     }
     for (auto& c : collectors_) { c->busy = false; c->prefilled = false; c->games.clear(); c->release_buffers(); }
     for (DevBuf* b : {&ts_src_, &ts_dst_, &ts_act_, &ts_status_, &ts_topa_, &ts_topp_, &ts_v_, &g_rows_, &g_stage_s_,
@@ -510,6 +517,14 @@ class GameContext {
   }
 
   int FuseMax() { need_env(); return goenv_get_fuse_max(env_->ctx()); }
+  // offline mode: rows whose owed moves the device rejected although the record's legal prefix said otherwise
+  // (0 unless the host's bookkeeping and the boards have diverged); synchronises the stream
+  int OfflineBadMoves() {
+    need_env();
+    int32_t n = 0;
+    chk(goenv_offline_bad_moves(env_->ctx(), &n, env_->stream()), "goenv_offline_bad_moves");
+    return n;
+  }
 
   uint64_t StatsPtr() { need_env(); return reinterpret_cast<uint64_t>(goenv_stats_ptr(env_->ctx())); }
 
@@ -1649,6 +1664,7 @@ PYBIND11_MODULE(go_game, m) {
       .def("Stats", &GameContext::Stats)
       .def("StatsPtr", &GameContext::StatsPtr)
       .def("FuseMax", &GameContext::FuseMax)
+      .def("OfflineBadMoves", &GameContext::OfflineBadMoves)
       .def("HostTimes", &GameContext::HostTimes, py::arg("reset") = false)
       .def("SearchInfo", &GameContext::SearchInfo);
 

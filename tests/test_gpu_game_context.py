@@ -94,6 +94,9 @@ def check_offline_streams(go, device, golden, full_batches=False):
                 streams[g].append([int(h[k][0, r]) for k in LABELS] + [[int(a) for a in h["offline_a"][0, r]]] +
                                   ["%016x" % fnv_planes(FNV_SEED, h["s"][0, r].reshape(-1))])
             gc.Steps(infos)
+        # the host never asks the device whether a record move is legal (it knows each record's legal prefix):
+        # the device, which checks every move all the same, must never have disagreed
+        assert gc.OfflineBadMoves() == 0
         gc.Stop()
         for g in range(B):
             want = run["streams"][str(g)][:n_check]
