@@ -1696,12 +1696,27 @@ int goenv_offline_batch(goenv_ctx* c, const void* block, int count, int k_future
   if (moves_offset & 1) return fail("goenv_offline_batch: moves_offset must be even");
   ON_DEVICE_OF(c);
   if (count == 0) return stage_commit(c, block, stream);
+  const int row_w = OFFLINE_ROW_HEAD + 2 * k_future;
+  if (block == c->stage_host[c->stage_next]) {
+    // a block of the staging ring is host memory of known size: check what the kernel will index with before
+    // it does (an out-of-range row would be a device fault, not an error code)
+    const size_t cap = c->stage_cap[c->stage_next];
+    if (moves_offset < (size_t)count * row_w * 4 || moves_offset > cap)
+      return fail("goenv_offline_batch: moves_offset does not lie behind the rows, inside the block");
+    const size_t n_moves_max = (cap - moves_offset) / 2;
+    const int32_t* rows = static_cast<const int32_t*>(block);
+    for (int r = 0; r < count; ++r) {
+      const int32_t* row = rows + (size_t)r * row_w;
+      const uint32_t n = (uint32_t)row[1] >> 8, off = (uint32_t)row[2];
+      if (row[0] < 0 || row[0] >= c->n) return fail("goenv_offline_batch: a row names a board outside the context");
+      if ((size_t)off + n > n_moves_max) return fail("goenv_offline_batch: a row's moves run past the end of the block");
+    }
+  }
   PlyParams P = make_params(c, 0u, nullptr, nullptr, feat_out, legal_out, nullptr, nullptr);
   P.n = count;
   P.max_ply = 0;  // a replayed record is not subject to the playout ply cap
   P.zero_first = pick_zero_first(c, count);
   if (labels) P.meta = *labels;
-  const int row_w = OFFLINE_ROW_HEAD + 2 * k_future;
   const int nw = feat_out ? pick_nw_features(c, count) : pick_nw(c, count);
   GO_LAUNCH(nw, k_offline, count, S(stream), P, (const int32_t*)block, row_w, k_future,
             (const int16_t*)((const char*)block + moves_offset), offline_a_out, c->bad_moves);

@@ -381,6 +381,28 @@ class GoEnv:
         self._chk(self.lib.goenv_copy_rows(self._h, _ptr(src), _ptr(src_rows), _ptr(dst), _ptr(dst_rows), int(n), rb,
                                            self._stream()))
 
+    def stage_acquire(self, nbytes):
+        """goenv_stage_acquire: the next pinned host block of the staging ring, as a writable numpy uint8 view."""
+        import numpy as np
+        p = C.c_void_p()
+        self._chk(self.lib.goenv_stage_acquire(self._h, int(nbytes), C.byref(p)))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(int(nbytes),)), p.value
+
+    def offline_batch(self, block_ptr, count, k_future, moves_offset, feat_out=None, legal_out=None, labels=None,
+                      offline_a_out=None):
+        """goenv_offline_batch: block_ptr = address of the packed rows (a stage_acquire block, or device memory)."""
+        self._check_rows(count, feat_out=feat_out, legal_out=legal_out)
+        self._check(offline_a_out, torch.int64, (count, k_future), "offline_a_out")
+        m = SampleOut.from_tensors(labels, count=count, device=self.device) if labels is not None else None
+        self._chk(self.lib.goenv_offline_batch(self._h, C.c_void_p(block_ptr), int(count), int(k_future), int(moves_offset),
+                                               _ptr(feat_out), _ptr(legal_out), C.byref(m) if m is not None else None,
+                                               _ptr(offline_a_out), self._stream()))
+
+    def offline_bad_moves(self):
+        n = C.c_int32(0)
+        self._chk(self.lib.goenv_offline_bad_moves(self._h, C.byref(n), self._stream()))
+        return n.value
+
     def playout(self, moves_out=None, nmoves_out=None):
         max_record = 0
         if moves_out is not None:

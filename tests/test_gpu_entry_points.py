@@ -308,3 +308,109 @@ def test_copy_rows_gathers_and_scatters(goenv):
     with pytest.raises(goenv.GoEnvError):
         env.copy_rows(torch.zeros(4, 8, device=dev), torch.zeros(4, 9, device=dev))
     env.close()
+
+
+def _pack_offline_rows(buf, rows, k):
+    """rows: dicts(board, aug, reset, handi, moves, labels[8], offline_a[k]) -> the block layout of
+    goenv_offline_batch (include/goenv.h); returns moves_offset."""
+    n, row_w = len(rows), 12 + 2 * k
+    words = buf[:n * row_w * 4].view(np.int32).reshape(n, row_w)
+    moves_off = n * row_w * 4
+    mv = buf[moves_off:].view(np.int16)
+    at = 0
+    for r, d in enumerate(rows):
+        words[r, 0] = d["board"]
+        words[r, 1] = d["aug"] | (8 if d["reset"] else 0) | (d["handi"] << 4) | (len(d["moves"]) << 8)
+        words[r, 2] = at
+        words[r, 3] = 0
+        words[r, 4:12] = d["labels"]
+        words[r, 12:].view(np.int64)[:] = d["offline_a"]
+        mv[at:at + len(d["moves"])] = d["moves"]
+        at += len(d["moves"])
+    return moves_off
+
+
+@pytest.mark.parametrize("device_block", [False, True])
+def test_offline_batch_through_the_c_abi(goenv, device_block):
+    """goenv_offline_batch: per row an optional reset + handicap, the row's record moves, then planes under the
+    row's D4 code, mask and the host's labels -- one launch -- against oracle boards doing the same
+    (OfflineLoader reload / next / extract, go/offpolicy_loader.cc:70-145).  Rows are read in place from a
+    block of the pinned staging ring, or from device memory."""
+    g = load_golden("sample1.json")
+    rec = g["moves"][:120]
+    B, k, seed = 37, 3, 5
+    env, oracles = midgame(goenv, B, seed, 40)
+    rng = np.random.RandomState(9)
+    perm = rng.permutation(B)
+    bad_rows = 0
+    for rnd in range(3):
+        rows = []
+        for r, b in enumerate(perm):
+            b = int(b)
+            kind = (r + rnd) % 4
+            d = dict(board=b, aug=int(rng.randint(8)), reset=kind in (0, 1), handi=[0, 4, 0, 0][kind],
+                     labels=[int(x) for x in rng.randint(-5, 1000, 8)], offline_a=[int(x) for x in rng.randint(0, 361, k)])
+            d["labels"][3] = int(rng.randint(2))
+            o = oracles[b]
+            if d["reset"]:
+                o.clear()
+                o.apply_handicap(d["handi"])
+                # after a handicap WHITE is to move: the record's first move then plays as white, as in the reference
+                d["moves"] = rec[:int(rng.randint(0, 90))]
+            elif kind == 2:
+                d["moves"] = []                                       # nothing owed: planes of the position as it stands
+            else:
+                idx = np.flatnonzero(o.candidates())
+                d["moves"] = [int(idx[rng.randint(len(idx))])] if len(idx) else [-1]
+            applied = 0
+            for m in d["moves"]:
+                if not o.forward(int(m))[0]:
+                    break
+                applied += 1
+            d["want_applied_all"] = applied == len(d["moves"])
+            rows.append(d)
+        nbytes = B * (12 + 2 * k) * 4 + 2 * sum(len(d["moves"]) for d in rows) + 64
+        buf, ptr = env.stage_acquire(nbytes)
+        moves_off = _pack_offline_rows(buf, rows, k)
+        if device_block:
+            dev = torch.from_numpy(buf.copy()).to(env.device)
+            ptr_used = dev.data_ptr()
+        else:
+            ptr_used = ptr
+        feat = torch.full((B, 25, 19, 19), -2.0, device=env.device)
+        legal = torch.full((B, 361), 7, dtype=torch.uint8, device=env.device)
+        labels = {kk: torch.zeros(B, dtype=goenv.SampleOut.DTYPES[kk], device=env.device) for kk in goenv.SampleOut.DTYPES}
+        offa = torch.zeros(B, k, dtype=torch.int64, device=env.device)
+        env.offline_batch(ptr_used, B, k, moves_off, feat, legal, labels, offa)
+        if device_block:                                               # the ring block was not consumed: hand it back
+            env.offline_batch(ptr, 0, k, moves_off)
+        torch.cuda.synchronize()
+        f, lg = feat.cpu().numpy().reshape(B, -1), legal.cpu().numpy()
+        lab = {kk: v.cpu().numpy() for kk, v in labels.items()}
+        oa = offa.cpu().numpy()
+        st = {kk: v.cpu().numpy() for kk, v in env.get_state().items()}
+        names = ["id", "seq", "game_counter", "last_terminal", "move_idx", "winner", "aug_code", "game_record_idx"]
+        for r, d in enumerate(rows):
+            o = oracles[d["board"]]
+            w = "round %d row %d board %d" % (rnd, r, d["board"])
+            assert_planes_equal(f[r], o.extract(d["aug"]), w)
+            assert np.array_equal(lg[r], o.legal()), w
+            assert_canon_equal({kk: v[d["board"]] for kk, v in st.items()}, o.canonical(), w)
+            assert [int(lab[nm][r]) for nm in names] == d["labels"], w
+            assert oa[r].tolist() == d["offline_a"], w
+        bad_rows += sum(0 if d["want_applied_all"] else 1 for d in rows)
+        # (the sample1 prefix is legal from an empty board, not always after four handicap stones: such a row
+        # stops at the rejected move, exactly as the oracle did above, and is counted)
+        assert env.offline_bad_moves() == bad_rows
+    # argument errors: a row naming a board outside the context, moves past the end of the block
+    buf, ptr = env.stage_acquire(4096)
+    rows = [dict(board=B + 3, aug=0, reset=False, handi=0, moves=[], labels=[0] * 8, offline_a=[0] * k)]
+    off = _pack_offline_rows(buf, rows, k)
+    with pytest.raises(goenv.GoEnvError, match="outside the context"):
+        env.offline_batch(ptr, 1, k, off)
+    rows[0]["board"] = 0
+    off = _pack_offline_rows(buf, rows, k)
+    buf[:8].view(np.int32)[1] = 1 << 30                                 # claims 4 M moves
+    with pytest.raises(goenv.GoEnvError, match="past the end"):
+        env.offline_batch(ptr, 1, k, off)
+    env.close()
