@@ -896,6 +896,13 @@ __device__ __forceinline__ void write_features(BoardLds<NW>& L, const Geo<NW>& g
   // two waves per board: the one storing wave has 12 planes to compute and store while wave 0 runs the
   // distance transform, which takes half as long -- wave 0 takes the 11 constant planes after it
   constexpr bool ZEROS_WAVE0 = NW == 2;
+#ifdef GOENV_SPLIT_ASC
+  // probe: with two waves per board each wave's stores form ONE ascending contiguous run -- wave 1 planes 0..13,
+  // wave 0 (after the distance transform) planes 14..24 -- the "contiguous halves" pattern of tools/store_bench.hip
+  constexpr bool ASC = NW == 2;
+#else
+  constexpr bool ASC = false;
+#endif
   const int sw = NW > 1 ? g.wave - 1 : 0;                 // this wave's index among them (-1: wave 0)
   if (NW == 1 || g.wave > 0) {
     GO_UNROLL
@@ -924,7 +931,7 @@ __device__ __forceinline__ void write_features(BoardLds<NW>& L, const Geo<NW>& g
       GO_PLANE(9, col == 0 ? 1.f : 0.f);
       GO_PLANE(10, mine ? hh : 0.f);
       GO_PLANE(11, theirs ? hh : 0.f);
-      if (ZEROS && !ZEROS_WAVE0) zero_range<WT>(out + 12 * NPTS, 2 * NPTS, lane);   // BORDER, POSITION_MARK: never filled
+      if (ZEROS && (ASC || !ZEROS_WAVE0)) zero_range<WT>(out + 12 * NPTS, 2 * NPTS, lane);   // BORDER, POSITION_MARK: never filled
     }
     if (ZEROS && !ZEROS_WAVE0) {                                // planes 16..24: never filled
       if (4 % NS == sw) zero_range<WT>(out + 16 * NPTS, 4 * NPTS, lane);
@@ -934,7 +941,7 @@ __device__ __forceinline__ void write_features(BoardLds<NW>& L, const Geo<NW>& g
 #ifndef GOENV_ABLATE_DIST
   if (g.wave == 0) distance_lines(L, lane, wb, ww, aug);
 #endif
-  if (ZEROS && ZEROS_WAVE0 && g.wave == 0) {
+  if (ZEROS && ZEROS_WAVE0 && !ASC && g.wave == 0) {
     zero_range<WT>(out + 12 * NPTS, 2 * NPTS, lane);
     zero_range<WT>(out + 16 * NPTS, 9 * NPTS, lane);
   }
@@ -942,9 +949,9 @@ __device__ __forceinline__ void write_features(BoardLds<NW>& L, const Geo<NW>& g
   WSYNC();
   FSTAMP(11);
   // planes 14 / 15 straight from the distance tables (already in output order)
-  if (g.wave == 0 || (NW > 1 && g.wave == 1)) {
-    const bool second = NW > 1 && g.wave == 1;                       // wave 1 takes plane 15
-    for (int pass = 0; pass < (NW == 1 ? 2 : 1); ++pass) {
+  if (g.wave == 0 || (NW > 1 && !ASC && g.wave == 1)) {
+    const bool second = NW > 1 && !ASC && g.wave == 1;               // wave 1 takes plane 15
+    for (int pass = 0; pass < ((NW == 1 || ASC) ? 2 : 1); ++pass) {
       const bool opp_plane = second || pass == 1;
       const uint8_t* dt = L.dist[(opp_plane ? opp : our) - 1];
       const bool present = opp_plane ? has_opp : has_our;
@@ -953,6 +960,7 @@ __device__ __forceinline__ void write_features(BoardLds<NW>& L, const Geo<NW>& g
       if (opp_plane) GO_PLANE(15, present ? (float)dd : 10000.f);
       else GO_PLANE(14, present ? (float)dd : 10000.f);
     }
+    if (ASC && ZEROS) zero_range<WT>(out + 16 * NPTS, 9 * NPTS, lane);
   }
 #undef GO_PLANE
 #undef FSTAMP
