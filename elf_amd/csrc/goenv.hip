@@ -1129,7 +1129,7 @@ struct DeviceScope {
 
 extern "C" {
 
-int goenv_version(void) { return 2; }
+int goenv_version(void) { return 3; }
 
 const char* goenv_last_error(void) { return g_err.c_str(); }
 
