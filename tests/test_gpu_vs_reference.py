@@ -188,3 +188,36 @@ def test_generator_rings_against_the_reference(goenv):
     assert restarts >= boards
     ref.check(None, None, host_state(env), None, None, None, "records after the last launch")
     env.close()
+
+
+def test_move_filters_against_the_reference(goenv):
+    """SURVEY 8f-3 on the GPU box against the reference's own IsSelfAtari / IsMoveGivingSimpleKo /
+    FindAllCandidateMoves / find_only_liberty / find_two_liberties / CheckLadder (go/board.cc:168-391,685-715,
+    1042-1081; goref_tactics): goenv_tactics for all 361 points of 192 boards at several stages of policy games."""
+    boards, seed = 192, 57
+    env = goenv.GoEnv(boards, seed=seed, max_ply=722)
+    ref = RefBatch(boards)
+    acts = env.new(torch.int32)
+    dev = env.device
+    hits = dict(self_atari=0, gives_ko=0, ladder=0)
+    ply = 0
+    for stop, thres in ((30, 1), (90, 2), (170, 3), (260, 1), (340, 5)):
+        while ply < stop:
+            env.ply(goenv.F_RANDOM_POLICY, actions_out=acts)
+            ref.check(acts.cpu().numpy(), None, None, None, None, None, "ply %d" % ply)
+            ply += 1
+        out = dict(self_atari=torch.full((boards, 361), -7, dtype=torch.int16, device=dev),
+                   gives_ko=torch.full((boards, 361), 9, dtype=torch.uint8, device=dev),
+                   cand=torch.full((boards, 361), 9, dtype=torch.uint8, device=dev),
+                   libs=torch.full((boards, 361, 2), -7, dtype=torch.int16, device=dev),
+                   ladder=torch.full((boards, 361), -7, dtype=torch.int16, device=dev))
+        got = {k: v.cpu().numpy() for k, v in env.tactics(thres, **out).items()}
+        for b in range(boards):
+            want = ref.board(b).tactics(thres)
+            for k in want:
+                assert np.array_equal(got[k][b], want[k]), "ply %d board %d: %s" % (ply, b, k)
+            hits["self_atari"] += int((want["self_atari"] > 0).sum())
+            hits["gives_ko"] += int(want["gives_ko"].sum())
+            hits["ladder"] += int((want["ladder"] > 0).sum())
+    assert hits["self_atari"] > 1000 and hits["gives_ko"] > 20 and hits["ladder"] > 20, hits
+    env.close()
