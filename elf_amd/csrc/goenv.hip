@@ -727,6 +727,114 @@ __global__ __launch_bounds__(64 * NW) void k_generate(PlyParams P, int n_plies, 
   store_board(rec, g, lab, lastp, o, s);
 }
 
+#ifndef GOENV_PIPE_ABLATE
+#define GOENV_PIPE_ABLATE 0
+#endif
+// The same generator as a two-stage pipeline INSIDE the board's workgroup (goenv_device.h, PipeSnap): wave 0 plays ply
+// t + 1 while wave 1 writes the sample of ply t.  Same ring contents, bit for bit.
+__global__ __launch_bounds__(128) void k_generate_pipe(PlyParams P, int n_plies, int32_t* actions_ring, int pace_ticks) {
+  __shared__ BoardLds<1> L;
+  __shared__ PipeLds X;
+  if ((int)blockIdx.x >= P.n) return;
+  const int b = xcd_row(blockIdx.x, P.n, P.xcd_map);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int aug = P.aug ? (P.aug[b] & 7) : 0;
+  if (threadIdx.x == 0) { X.produced = 0; X.consumed = 0; }
+  for (int i = threadIdx.x; i < PIPE_LUT_N; i += 128) X.lut[i] = P.lut[i];
+  __syncthreads();   // the only barrier of the kernel
+#ifdef GOENV_STAMPS
+  unsigned long long acc_[6] = {0, 0, 0, 0, 0, 0}, tk_ = wall_clock64();
+#define PTICK(i) do { const unsigned long long n_ = wall_clock64(); acc_[i] += n_ - tk_; tk_ = n_; } while (0)
+#else
+#define PTICK(i) do { } while (0)
+#endif
+  if (wave == 0) {
+    Geo<1> g;
+    geo_init(g);
+    constexpr int K = Geo<1>::K;
+    BoardRec* rec = P.state + b;
+    Scalars s;
+    uint32_t lab[K], lastp[K];
+    Masks m;
+    Own<1> o;
+    load_record(rec, L, g, lab, lastp, s, m);
+    own_from_masks(g, m, o);
+    PTICK(0);
+    for (int t = 0; t < n_plies; ++t) {  // host-supplied bound, the same for both waves
+#if GOENV_PIPE_ABLATE == 2   // probe: no rules (the feature wave and the store stream alone)
+      const int a = -1;
+#else
+      if (s.done) {
+        if (!s.counted) account_game(P.stats, g.tid, s, tromp_taylor(L, g, lab), P.komi);
+        restart_in_place(L, g, lab, lastp, s, m, o);
+      }
+      const int a = ply_body<1, true>(L, g, lab, lastp, s, m, o, P, b, 0ll);
+      gather_masks(L, g, o, m);
+#endif
+      PTICK(1);
+      if (t >= PIPE_DEPTH) pipe_wait(&X.consumed, t - PIPE_DEPTH + 1);   // slot t % PIPE_DEPTH has been taken
+      PTICK(2);
+      snapshot_write(X.snap[t % PIPE_DEPTH], g, lab, lastp, s, o, a);
+      pipe_post(&X.produced, t + 1, g.lane);
+      PTICK(3);
+    }
+    store_board(rec, g, lab, lastp, o, s);
+  } else {
+    const int lane = (int)(threadIdx.x & 63);
+    int src[8];
+    for (int i = 0; i < 8; ++i) {
+      const int q = i < 4 ? 4 * lane + i : (lane < 26 ? 256 + 4 * lane : NPTS - 4) + (i - 4);
+      src[i] = aug ? d4_src(aug, q) : q;
+    }
+    unsigned long long next = 0;
+    for (int t = 0; t < n_plies; ++t) {
+      PTICK(0);
+      pipe_wait(&X.produced, t + 1);
+      PTICK(1);
+      SnapRegs r;
+      snapshot_load(X.snap[t % PIPE_DEPTH], lane, src, r);
+      pipe_post(&X.consumed, t + 1, lane);
+      PTICK(2);
+      if (pace_ticks) {
+        // rate limiter on the 100-MHz wall clock: a board starts a sample at most once per `pace_ticks`.  The memory side
+        // takes this store pattern FASTER when it is offered just below what it can sustain than when every wave
+        // pushes as hard as it can (tools/store_bench.hip mode 8: 5.5 TB/s free-running, 6.0 TB/s paced).
+        unsigned long long now = wall_clock64();
+        for (int spin = 0; spin < 4096 && now < next; ++spin) {   // bounded: a wave always gets out
+          __builtin_amdgcn_s_sleep(1);
+          now = wall_clock64();
+        }
+        // a fixed schedule, so that a sample that started late does not delay those after it; dropped after a long gap
+        next = (now > next + 2ull * (unsigned long long)pace_ticks) ? now + (unsigned long long)pace_ticks
+                                                                     : next + (unsigned long long)pace_ticks;
+      }
+      PTICK(3);
+      const size_t row = (size_t)t * P.n + b;
+      if (actions_ring && lane == 0) actions_ring[row] = r.action;
+      uint8_t* lg = P.legal ? P.legal + row * NPTS : nullptr;
+#if GOENV_PIPE_ABLATE == 1   // probe: no samples written (the rules wave alone)
+      if (false) {
+#else
+      if (P.feat) {
+#endif
+        if (P.zero_first & 4) snapshot_expand<false>(r, X, lane, aug, src, P.feat + row * GOENV_FEAT_FLOATS, lg);
+        else snapshot_expand<true>(r, X, lane, aug, src, P.feat + row * GOENV_FEAT_FLOATS, lg);
+      } else if (lg) {
+        for (int k = 0; k < NWORDS; ++k) {
+          const int p = lane + 64 * k;
+          if (p < NPTS) lg[p] = (uint8_t)((r.lg[k] >> lane) & 1ull);
+        }
+      }
+    }
+  }
+#ifdef GOENV_STAMPS
+  PTICK(4);   // the feature wave: expansion of the last sample; the rules wave: the record store
+  if (P.stamps && (threadIdx.x & 63) == 0)
+    for (int i = 0; i < 6; ++i) P.stamps[(size_t)blockIdx.x * 32 + wave * 16 + i] = acc_[i];
+#endif
+#undef PTICK
+}
+
 // Replay of given move lists (SGF records packed on the host): row b applies
 // moves[b*stride + 0 .. nmoves[b]) to its board with GoState::forward semantics and stops at the
 // first illegal move (go/offpolicy_loader.cc:120-126); napplied[b] = moves applied.  The board
@@ -1016,6 +1124,24 @@ __global__ __launch_bounds__(64) void k_tactics(const BoardRec* state, int n_tot
 // host side
 // ----------------------------------------------------------------------------------------------
 
+// The rate limiter of k_generate_pipe tunes itself: the offered store rate that the memory side takes best differs from
+// card to card by a few per cent (cliff measured at 6.0 .. 6.5 ns per board-ply), and offering more than that costs 10 %
+// (profiles/r03_pipe_generator.md).  goenv_generate times its own launches with events (recorded around the kernel, read
+// back later without waiting) and moves between a few candidate paces: every candidate twice in turn, then the best one,
+// with a neighbour tried now and then.  The pace changes WHEN samples are written, never what is written.
+struct GenTune {
+  static constexpr int NC = 6, NPEND = 8;
+  // ns per board-ply offered: 36,465 B / 6.65 ns = 5.48 TB/s is the safe side of every cliff seen
+  static constexpr float cand[NC] = {6.05f, 6.25f, 6.45f, 6.65f, 6.90f, 7.30f};
+  static constexpr int SAFE = 3;
+  float est[NC];          // us per ply, running estimate (0: none yet)
+  int samples[NC], launched[NC];
+  int launches;
+  struct Pend { hipEvent_t e0, e1; int cand, plies, busy; } pend[NPEND];
+  int events_ready;
+};
+constexpr float GenTune::cand[GenTune::NC];
+
 struct goenv_ctx {
   int device;
   int n;
@@ -1044,6 +1170,12 @@ struct goenv_ctx {
   int stage_next;
   int32_t* bad_moves;                  // device counter of goenv_offline_batch rows that hit a rejected move
   int planes_preset;                   // goenv_set_constant_planes_preset
+  int gen_pipe;                        // goenv_generate through k_generate_pipe: -1 = where all boards are resident
+                                       // (default), 0 / 1 pinned (GOENV_GEN_PIPE)
+  int gen_pace_ns;                     // its rate limiter, ns between two samples of a board: -1 = tuned (default),
+                                       // else pinned, 0 = none (GOENV_GEN_PACE_NS)
+  int gen_resident;                    // boards of k_generate_pipe that the device holds at once (0: not asked yet)
+  GenTune tune;
 };
 
 // The standalone feature kernel has no rules phase that staggers its waves' stores: mid-size
@@ -1155,6 +1287,10 @@ int goenv_create(int device, int n_boards, uint64_t seed, int64_t board_id_base,
   // the sampler as a small launch of its own is faster (4,096: 34.2 against 35.0 us; 8,192: 59.7 against 78.2)
   c->fuse_max = 3072;
   if (const char* e = getenv("GOENV_FUSE_MAX")) c->fuse_max = atoi(e);
+  c->gen_pipe = -1;
+  c->gen_pace_ns = -1;
+  if (const char* e = getenv("GOENV_GEN_PIPE")) c->gen_pipe = atoi(e) ? 1 : 0;
+  if (const char* e = getenv("GOENV_GEN_PACE_NS")) c->gen_pace_ns = atoi(e) < 0 ? -1 : atoi(e);
   if (const char* e = getenv("GOENV_WAVES_PER_BOARD")) {
     const int v = atoi(e);
     if (v == 1 || v == 2 || v == 3 || v == 6) c->nw = v;
@@ -1164,6 +1300,8 @@ int goenv_create(int device, int n_boards, uint64_t seed, int64_t board_id_base,
   std::vector<float> lut(HIST_LUT_N);
   for (int d = 0; d < HIST_LUT_N; ++d) lut[d] = (float)exp((double)(-d) / 10.0);
   lut[HIST_LUT_N - 1] = 0.f;  // ages >= 2047 plies: exp(-204.7) underflows float to 0
+  for (int d = PIPE_LUT_N - 1; d < HIST_LUT_N; ++d)
+    if (lut[d] != 0.f) { delete c; return fail("goenv_create: history table is not zero beyond PIPE_LUT_N"); }
   c->lut1 = lut[1];
   hipError_t e;
   const char* what = "goenv_create: hipMalloc";
@@ -1215,6 +1353,8 @@ int goenv_destroy(goenv_ctx* c) {
     if (c->stage_event[i]) (void)hipEventDestroy(c->stage_event[i]);
   }
   if (c->bad_moves) (void)hipFree(c->bad_moves);
+  if (c->tune.events_ready)
+    for (int i = 0; i < GenTune::NPEND; ++i) { (void)hipEventDestroy(c->tune.pend[i].e0); (void)hipEventDestroy(c->tune.pend[i].e1); }
   if (c->parts_ready) {
     for (int i = 0; i < GOENV_MAX_PARTS; ++i) (void)hipStreamDestroy(c->part_stream[i]);
     for (int i = 0; i <= GOENV_MAX_PARTS; ++i) (void)hipEventDestroy(c->part_event[i]);
@@ -1416,7 +1556,8 @@ extern "C" int goenv_diag_generate(goenv_ctx* c, int n_plies, float* feat_ring, 
                             nullptr, nullptr);
   P.stamps = stamps;
   const int nw = c->nw ? c->nw : (c->n <= 4096 ? 2 : 3);
-  GO_LAUNCH(nw, k_generate, c->n, S(stream), P, n_plies, (int32_t*)nullptr);
+  if (c->gen_pipe > 0) hipLaunchKernelGGL(k_generate_pipe, dim3(c->n), dim3(128), 0, S(stream), P, n_plies, (int32_t*)nullptr, (c->gen_pace_ns > 0 ? c->gen_pace_ns : 0) / 10);
+  else GO_LAUNCH(nw, k_generate, c->n, S(stream), P, n_plies, (int32_t*)nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1795,6 +1936,38 @@ int goenv_playout(goenv_ctx* c, int16_t* moves_out, int max_record, int32_t* nmo
   return 0;
 }
 
+// results of timed launches that have finished (never waits)
+static void gen_tune_collect(GenTune& t) {
+  for (int i = 0; i < GenTune::NPEND; ++i) {
+    GenTune::Pend& p = t.pend[i];
+    if (!p.busy || hipEventQuery(p.e1) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess && ms > 0.f) {
+      const float us = ms * 1e3f / (float)p.plies;
+      t.est[p.cand] = t.samples[p.cand] ? 0.5f * (t.est[p.cand] + us) : us;
+      t.samples[p.cand] += 1;
+    }
+    p.busy = 0;
+  }
+  (void)hipGetLastError();   // hipEventQuery reports "not ready" as an error
+}
+
+// the candidate of the next launch
+static int gen_tune_pick(GenTune& t) {
+  for (int round = 1; round <= 2; ++round)          // every candidate twice, in turn
+    for (int i = 0; i < GenTune::NC; ++i)
+      if (t.launched[i] < round) return i;
+  int best = -1;
+  for (int i = 0; i < GenTune::NC; ++i)
+    if (t.samples[i] && (best < 0 || t.est[i] < t.est[best])) best = i;
+  if (best < 0) return GenTune::SAFE;               // nothing has come back yet
+  if (t.launches % 16 == 15) {                      // now and then a neighbour: the card's state drifts
+    const int nb = best + (((t.launches >> 4) & 1) ? 1 : -1);
+    if (nb >= 0 && nb < GenTune::NC) return nb;
+  }
+  return best;
+}
+
 int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* feat_ring, uint8_t* legal_ring,
                    int32_t* actions_ring, void* stream) {
   if (!c) return fail("goenv_generate: ctx is NULL");
@@ -1803,10 +1976,75 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
   if (n_plies == 0) return 0;
   PlyParams P = make_params(c, GOENV_F_RANDOM_POLICY | GOENV_F_AUTO_RESTART, nullptr, aug_codes, feat_ring, legal_ring,
                             nullptr, nullptr);
-  // persistent launch: boards drift apart, two waves per board hide the rest (tools/time_generate.py)
-  const int nw = c->nw ? c->nw : (c->n <= 4096 ? 2 : 3);
-  GO_LAUNCH(nw, k_generate, c->n, S(stream), P, n_plies, actions_ring);
+  // Up to the number of boards that the device holds at once (2,304 on an MI355X): a rules wave and a feature wave per
+  // board, pipelined through LDS, the feature waves rate-limited (k_generate_pipe; 1,024 boards: 7.7 -> 6.9 us per ply,
+  // 512 .. 2,048 boards: -18 %).  Beyond, workgroups run in rounds and a clock-driven schedule has no meaning: two or three
+  // waves per board that share rules and stores (k_generate; tools/time_generate.py).
+  if (!c->gen_resident) {
+    int per_cu = 0, cus = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_generate_pipe, 128, 0));
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    c->gen_resident = per_cu * cus > 0 ? per_cu * cus : -1;
+  }
+  const bool resident = c->n <= c->gen_resident;
+  const bool pipe = c->nw ? false : (c->gen_pipe < 0 ? resident : c->gen_pipe != 0);
+  if (!pipe) {
+    const int nw = c->nw ? c->nw : (c->n <= 4096 ? 2 : 3);
+    GO_LAUNCH(nw, k_generate, c->n, S(stream), P, n_plies, actions_ring);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  int pace_ticks = 0;   // 10-ns ticks of the wall clock
+  GenTune::Pend* timed = nullptr;
+  if (c->gen_pace_ns >= 0) {
+    pace_ticks = resident ? c->gen_pace_ns / 10 : 0;
+  } else if (resident && P.feat) {
+    GenTune& t = c->tune;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream) (void)hipStreamIsCapturing(S(stream), &cap);
+    int cand = GenTune::SAFE;
+    if (cap == hipStreamCaptureStatusNone && n_plies >= 8) {   // (no event inside a capture; short launches say little)
+      if (!t.events_ready) {
+        for (int i = 0; i < GenTune::NPEND; ++i) {
+          HIPCHK(hipEventCreate(&t.pend[i].e0));
+          HIPCHK(hipEventCreate(&t.pend[i].e1));
+        }
+        t.events_ready = 1;
+      }
+      gen_tune_collect(t);
+      cand = gen_tune_pick(t);
+      for (int i = 0; i < GenTune::NPEND && !timed; ++i)
+        if (!t.pend[i].busy) timed = &t.pend[i];
+      if (timed) { timed->cand = cand; timed->plies = n_plies; t.launched[cand] += 1; }
+      t.launches += 1;
+    } else {
+      for (int i = 0, best = -1; i < GenTune::NC; ++i)
+        if (t.samples[i] && (best < 0 || t.est[i] < t.est[best])) cand = best = i;
+    }
+    pace_ticks = (int)(GenTune::cand[cand] * (float)c->n / 10.f);
+  }
+  if (timed) HIPCHK(hipEventRecord(timed->e0, S(stream)));
+  hipLaunchKernelGGL(k_generate_pipe, dim3(c->n), dim3(128), 0, S(stream), P, n_plies, actions_ring, pace_ticks);
   HIPCHK(hipGetLastError());
+  if (timed) {
+    HIPCHK(hipEventRecord(timed->e1, S(stream)));
+    timed->busy = 1;
+  }
+  return 0;
+}
+
+// What the generator's self-tuning rate limiter has settled on: ns per board-ply offered (0: not in use or no result
+// yet), and its estimates per candidate in est_out[6] (us per ply, 0 = none).  Diagnostic.
+int goenv_generate_pace(goenv_ctx* c, float* pace_ns_per_board_out, float* est_out) {
+  if (!c) return fail("goenv_generate_pace: ctx is NULL");
+  GenTune& t = c->tune;
+  if (t.events_ready) gen_tune_collect(t);
+  int best = -1;
+  for (int i = 0; i < GenTune::NC; ++i) {
+    if (est_out) est_out[i] = t.samples[i] ? t.est[i] : 0.f;
+    if (t.samples[i] && (best < 0 || t.est[i] < t.est[best])) best = i;
+  }
+  if (pace_ns_per_board_out) *pace_ns_per_board_out = best < 0 ? 0.f : GenTune::cand[best];
   return 0;
 }
 

@@ -108,7 +108,20 @@ struct Geo {
 };
 
 #define GO_UNROLL _Pragma("unroll")
-#define WSYNC() __syncthreads()  // NW == 1: lowers to a wave-level fence
+// Board-wide synchronisation point.  NW == 1: the board is one wave, whose LDS operations are executed in order;
+// only the compiler and the wave's own outstanding LDS operations must be fenced -- no `s_barrier`, so that a
+// one-wave board can live inside a LARGER workgroup (k_generate_pipe: a rules wave beside feature waves).
+template <int NW>
+__device__ __forceinline__ void wsync() {
+  if (NW == 1) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  } else {
+    __syncthreads();
+  }
+}
+#define WSYNC() wsync<NW>()
 
 __device__ __forceinline__ int popc64(unsigned long long v) { return __popcll(v); }
 __device__ __forceinline__ uint32_t col_of(uint32_t v) { return (v >> 9) & 3u; }
@@ -692,8 +705,8 @@ __device__ __forceinline__ int d4_dest(int code, int p) {
 // Pass 1 (along y) is a bit trick on the 19-bit column occupancy, pass 2 (along x) the
 // reference's forward/backward min-plus sweep, fully unrolled in registers.
 // Results are stored at the OUTPUT index of each point (D4 code `aug` applied here).
-template <int NW>
-__device__ __forceinline__ void distance_lines(BoardLds<NW>& L, int lane, const unsigned long long wb[NWORDS + 1],
+template <class LDS>
+__device__ __forceinline__ void distance_lines(LDS& L, int lane, const unsigned long long wb[NWORDS + 1],
                                                const unsigned long long ww[NWORDS + 1], int aug) {
   const bool white_lane = lane >= 32;
   const int y = lane & 31;
@@ -964,6 +977,180 @@ __device__ __forceinline__ void write_features(BoardLds<NW>& L, const Geo<NW>& g
   }
 #undef GO_PLANE
 #undef FSTAMP
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pipelined generator (k_generate_pipe): a board's workgroup is ONE rules wave (the NW == 1 code above, no
+// `s_barrier` inside) and ONE feature wave.  The rules wave leaves the position it has just reached as a
+// snapshot in LDS (its label and age tables, raw) and goes on with the next ply; the feature wave expands the snapshot into
+// the sample's planes, mask and move.  The two waves meet at no barrier: a ring of PIPE_DEPTH snapshots and two LDS
+// counters (produced / consumed) let the rules wave run ahead through the plies that are cheap for it.  The feature wave
+// issues no load from memory at all (`vmcnt` counts loads and stores in one queue on this part: a wave that
+// waits for a load waits for every plane store in front of it), and it writes a sample as ONE ascending run.
+struct __attribute__((aligned(16))) PipeSnap {
+  uint32_t raw[TAB_N];                  // label (colour, liberty class) | last_placed << 16 of every point, board order
+  unsigned long long legal[NWORDS];     // legal mask of the side to move
+  int32_t ply, next, ko, action;        // ko = GetSimpleKoLocation or -1
+};
+
+constexpr int PIPE_DEPTH = 4;           // snapshots in flight between the two waves
+// (float)exp(-d / 10.0) is 0 from d = 1040 on: the part of the history table that is not, kept in LDS so that the rules
+// wave's loop holds no load from memory (its loads would wait behind its own plane stores: one `vmcnt` queue)
+constexpr int PIPE_LUT_N = 1056;
+struct __attribute__((aligned(16))) PipeLds {
+  float lut[PIPE_LUT_N];
+  PipeSnap snap[PIPE_DEPTH];
+  uint8_t dist[2][TAB_N];               // the feature wave's distance tables
+  int32_t produced, consumed;           // snapshots written by the rules wave / taken by the feature wave so far
+};
+
+// Wait (bounded: a wave always gets out) until the LDS counter has reached `want`.
+__device__ __forceinline__ void pipe_wait(const int32_t* counter, int want) {
+  int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  for (int spin = 0; v < want && spin < (1 << 24); ++spin) {
+    __builtin_amdgcn_s_sleep(2);
+    v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void pipe_post(int32_t* counter, int value, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // a wave's LDS operations are executed in order
+  if (lane == 0) __hip_atomic_store(counter, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Inverse of d4_dest: the board point that lands on output index q under a D4 code.
+__device__ __forceinline__ int d4_src(int code, int q) {
+  int rx = q / BS, ry = q - rx * BS;
+  if ((code >> 2) == 1) { const int t = rx; rx = ry; ry = t; }
+  const int rot = code & 3;
+  int x, y;
+  if (rot == 1) { x = BS - 1 - ry; y = rx; }
+  else if (rot == 2) { x = BS - 1 - rx; y = BS - 1 - ry; }
+  else if (rot == 3) { x = ry; y = BS - 1 - rx; }
+  else { x = rx; y = ry; }
+  return x * BS + y;
+}
+
+// What the feature wave keeps of a snapshot (the slot is handed back as soon as this is loaded).
+struct SnapRegs {
+  unsigned long long wb[NWORDS + 1], ww[NWORDS + 1], lg[NWORDS];
+  uint32_t our;
+  int action, ply, ko;
+  uint32_t raw[8];   // the lane's eight OUTPUT points (4 lane .. 4 lane + 3, then 256 + 4 lane ..)
+};
+// src[i] = board point of the lane's i-th output point (constant over the launch: d4_src of the board's code)
+__device__ __forceinline__ void snapshot_load(const PipeSnap& S, int lane, const int src[8], SnapRegs& r) {
+  GO_UNROLL
+  for (int j = 0; j < NWORDS; ++j) r.lg[j] = uni64(S.legal[j]);
+  r.ply = __builtin_amdgcn_readfirstlane(S.ply);
+  r.our = (uint32_t)__builtin_amdgcn_readfirstlane(S.next);
+  r.ko = __builtin_amdgcn_readfirstlane(S.ko);
+  r.action = __builtin_amdgcn_readfirstlane(S.action);
+  GO_UNROLL
+  for (int i = 0; i < 8; ++i) r.raw[i] = S.raw[src[i]];
+  // colour ballots in board order for the distance transform
+  GO_UNROLL
+  for (int k = 0; k < NWORDS; ++k) {
+    const int p = lane + 64 * k;
+    const uint32_t col = p < NPTS ? col_of(S.raw[p]) : 0u;
+    r.wb[k] = __ballot(col == 1);
+    r.ww[k] = __ballot(col == 2);
+  }
+  r.wb[NWORDS] = 0; r.ww[NWORDS] = 0;
+}
+
+// Rules wave: the snapshot of the position (lab, lastp, s) whose masks are `o`, reached by `action`.
+__device__ __forceinline__ void snapshot_write(PipeSnap& S, const Geo<1>& g, const uint32_t lab[], const uint32_t lastp[],
+                                               const Scalars& s, const Own<1>& o, int action) {
+  GO_UNROLL
+  for (int k = 0; k < NWORDS; ++k)
+    if (g.p[k] < NPTS) S.raw[g.p[k]] = (lab[k] & 0xffffu) | (lastp[k] << 16);
+  if (g.lane == 0) {
+    GO_UNROLL
+    for (int k = 0; k < NWORDS; ++k) S.legal[k] = o.legal[k];
+    S.ply = s.ply;
+    S.next = s.next;
+    S.ko = (s.koage == 0 && s.ko >= 0) ? s.ko : -1;  // GetSimpleKoLocation, board.cc:337-344
+    S.action = action;
+  }
+}
+
+// Feature wave: BoardFeature::Extract (go/board_feature.cc:175-195) of a snapshot -- all 25 planes (ZEROS) or the 14
+// that carry data, in ascending order -- then the legal mask as bytes.
+template <bool ZEROS>
+__device__ __forceinline__ void snapshot_expand(const SnapRegs& r, PipeLds& X, int lane, int aug, const int src[8],
+                                                float* __restrict__ out, uint8_t* __restrict__ legal_out) {
+  const uint32_t our = r.our, opp = 3u - our;
+  int has = 0;
+  GO_UNROLL
+  for (int j = 0; j < NWORDS; ++j) { if (r.wb[j]) has |= 1; if (r.ww[j]) has |= 2; }
+  const bool has_our = (has >> (our - 1)) & 1, has_opp = (has >> (opp - 1)) & 1;
+  const int qa = 4 * lane;
+  const int qb = lane < 26 ? 256 + 4 * lane : NPTS - 4;
+  const bool act_b = lane <= 26;
+  uint32_t d[8];
+  float h[8];
+  GO_UNROLL
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t lab = r.raw[i] & 0xffffu;
+    d[i] = typ_of(lab);   // cls 1,2,3 <-> GetLibertyMap3binary :83-99
+    if (src[i] == r.ko) d[i] |= 16u;
+    int age = r.ply - (int)(r.raw[i] >> 16);
+    age = age < 0 ? 0 : (age > PIPE_LUT_N - 1 ? PIPE_LUT_N - 1 : age);   // lut[PIPE_LUT_N - 1 ..] == 0 (checked on the host)
+    const float hv = X.lut[age];
+    h[i] = lab ? hv : 0.f;
+  }
+#define GO_PLANE(pl, EXPR)                                                          \
+  do {                                                                              \
+    float v_[8];                                                                    \
+    GO_UNROLL                                                                       \
+    for (int i = 0; i < 8; ++i) {                                                   \
+      const uint32_t dd = d[i];                                                     \
+      const uint32_t col = dd & 3u, cls = (dd >> 2) & 3u;                           \
+      const bool mine = col == our, theirs = col == opp;                            \
+      const float hh = h[i];                                                        \
+      (void)cls; (void)mine; (void)theirs; (void)hh;                                \
+      v_[i] = (EXPR);                                                               \
+    }                                                                               \
+    store4<false>(out + (pl) * NPTS + qa, v_[0], v_[1], v_[2], v_[3]);              \
+    if (act_b) store4<false>(out + (pl) * NPTS + qb, v_[4], v_[5], v_[6], v_[7]);   \
+  } while (0)
+  GO_PLANE(0, (mine && cls == 1) ? 1.f : 0.f);
+  GO_PLANE(1, (mine && cls == 2) ? 1.f : 0.f);
+  GO_PLANE(2, (mine && cls != 1 && cls != 2) ? 1.f : 0.f);
+  GO_PLANE(3, (theirs && cls == 1) ? 1.f : 0.f);
+  GO_PLANE(4, (theirs && cls == 2) ? 1.f : 0.f);
+  GO_PLANE(5, (theirs && cls != 1 && cls != 2) ? 1.f : 0.f);
+  GO_PLANE(6, (dd & 16u) ? 1.f : 0.f);
+  GO_PLANE(7, mine ? 1.f : 0.f);
+  GO_PLANE(8, theirs ? 1.f : 0.f);
+  GO_PLANE(9, col == 0 ? 1.f : 0.f);
+  GO_PLANE(10, mine ? hh : 0.f);
+  GO_PLANE(11, theirs ? hh : 0.f);
+  if (ZEROS) zero_range<false>(out + 12 * NPTS, 2 * NPTS, lane);
+#if !defined(GOENV_PIPE_ABLATE) || GOENV_PIPE_ABLATE != 4   // probe 4: no distance transform
+  distance_lines(X, lane, r.wb, r.ww, aug);
+#endif
+  wsync<1>();
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool opp_plane = pass == 1;
+    const uint8_t* dt = X.dist[(opp_plane ? opp : our) - 1];
+    const bool present = opp_plane ? has_opp : has_our;
+    GO_UNROLL
+    for (int i = 0; i < 4; ++i) { d[i] = dt[qa + i]; d[4 + i] = dt[qb + i]; h[i] = 0.f; h[4 + i] = 0.f; }
+    if (opp_plane) GO_PLANE(15, present ? (float)dd : 10000.f);
+    else GO_PLANE(14, present ? (float)dd : 10000.f);
+  }
+#undef GO_PLANE
+  if (ZEROS) zero_range<false>(out + 16 * NPTS, 9 * NPTS, lane);
+  if (legal_out) {
+    GO_UNROLL
+    for (int k = 0; k < NWORDS; ++k) {
+      const int p = lane + 64 * k;
+      if (p < NPTS) legal_out[p] = (uint8_t)((r.lg[k] >> lane) & 1ull);
+    }
+  }
+  wsync<1>();   // the distance tables have been read before the next sample's transform rewrites them
 }
 
 template <int NW>

@@ -72,7 +72,7 @@ __device__ __forceinline__ void restore_image(BoardLds<1>& L, const Geo<1>& g, c
   GO_UNROLL
   for (int k = 0; k < Geo<1>::K; ++k)
     if (g.p[k] < NPTS) L.lab[g.c[k]] = (uint16_t)lab[k];
-  WSYNC();
+  wsync<1>();
 }
 
 // CheckLadderUseSearch (go/board.cc:203-317) as a loop: `lab`/L hold the position AFTER the
@@ -114,7 +114,7 @@ __device__ __forceinline__ int ladder_search(BoardLds<1>& L, TacticsLds& X, cons
               f.sc[5] = s.ko; f.sc[6] = s.koage; f.sc[7] = s.kocolor; f.sc[8] = s.ply;
               f.sc[9] = esc[1]; f.sc[10] = depth;
             }
-            WSYNC();
+            wsync<1>();
             mv = esc[0];
           }
         }
@@ -173,7 +173,7 @@ __device__ __forceinline__ void tactics(BoardLds<1>& L, TacticsLds& X, const Geo
   const uint32_t P = (uint32_t)s.next, O = 3u - P;
   // --- group tables
   for (int i = g.tid; i < TAB_N + 64; i += 64) { X.lmin[i] = 0xffffu; X.lmax[i] = 0u; X.stones[i] = 0u; }
-  WSYNC();
+  wsync<1>();
   const int sink = TAB_N + g.tid;
   GO_UNROLL
   for (int k = 0; k < K; ++k) {
@@ -194,7 +194,7 @@ __device__ __forceinline__ void tactics(BoardLds<1>& L, TacticsLds& X, const Geo
       atomicAdd(&X.stones[lab[k] & ROOT_MASK], 1u);
     }
   }
-  WSYNC();
+  wsync<1>();
   // --- per point
   int sa[K];
   bool slow[K], lad[K];

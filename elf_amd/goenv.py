@@ -78,6 +78,7 @@ _SIGS = {
     "goenv_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "goenv_playout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "goenv_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "goenv_generate_pace": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "goenv_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goenv_fast_score": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "goenv_topk_policy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
@@ -419,6 +420,13 @@ class GoEnv:
         self._check(aug_codes, torch.int32, (self.n,), "aug_codes")
         self._chk(self.lib.goenv_generate(self._h, int(n_plies), _ptr(aug_codes), _ptr(feat_ring), _ptr(legal_ring),
                                           _ptr(actions_ring), self._stream()))
+
+    def generate_pace(self):
+        """goenv_generate_pace: (ns per board-ply that the generator's rate limiter has settled on, [us per ply per
+        candidate pace])."""
+        pace, est = C.c_float(0), (C.c_float * 6)()
+        self._chk(self.lib.goenv_generate_pace(self._h, C.byref(pace), est))
+        return pace.value, list(est)
 
     def score(self, score_out=None, fast_out=None):
         self._check(score_out, torch.float32, (self.n,), "score_out")

@@ -167,9 +167,18 @@ def test_selections_and_sequencing_records(goenv):
     env.close()
 
 
-def test_generate_equals_per_ply_launches(goenv):
+@pytest.mark.parametrize("gen", ["default", "two_waves", "pipelined_unpaced", "pipelined_pinned_pace"])
+def test_generate_equals_per_ply_launches(goenv, monkeypatch, gen):
     """The persistent generator writes, slot by slot, exactly what the per-ply launches write
-    (moves, masks, planes), restarts included, and ends in the same state and statistics."""
+    (moves, masks, planes), restarts included, and ends in the same state and statistics -- through
+    each of its kernels: k_generate_pipe with the self-tuning rate limiter (the default up to the
+    number of resident boards), k_generate<2> (GOENV_GEN_PIPE=0), the pipelined kernel without and
+    with a pinned pace."""
+    env_vars = {"default": {}, "two_waves": {"GOENV_GEN_PIPE": "0"},
+                "pipelined_unpaced": {"GOENV_GEN_PIPE": "1", "GOENV_GEN_PACE_NS": "0"},
+                "pipelined_pinned_pace": {"GOENV_GEN_PIPE": "1", "GOENV_GEN_PACE_NS": "9000"}}[gen]
+    for k, v in env_vars.items():
+        monkeypatch.setenv(k, v)     # read by goenv_create
     B, T, seed = 48, 40, 21
     rounds = 4                       # a low ply cap forces restarts inside the rings
     a = goenv.GoEnv(B, seed=seed, max_ply=60)

@@ -1,0 +1,154 @@
+"""The pipelined generator kernel (k_generate_pipe: a rules wave and a feature wave per board, a ring of
+snapshots in LDS between them, rate-limited plane stores) against the two-waves-per-board kernel
+(GOENV_GEN_PIPE=0) and the CPU oracle: launches shorter than the snapshot ring, outputs left out, D4 codes,
+the constant planes preset, a launch inside a captured graph, and the self-tuning pace (which may change
+WHEN a sample is written, never a byte of it).  Bar: bit-exact."""
+import numpy as np
+import pytest
+
+from common import assert_planes_equal
+from oracle.pyoracle import OracleBoard
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def goenv():
+    from elf_amd import goenv as m
+    m.load_library()
+    assert torch.cuda.is_available()
+    return m
+
+
+def make(goenv, monkeypatch, pipe, n, seed, max_ply=80, pace=None):
+    monkeypatch.setenv("GOENV_GEN_PIPE", "1" if pipe else "0")
+    if pace is not None:
+        monkeypatch.setenv("GOENV_GEN_PACE_NS", str(pace))
+    else:
+        monkeypatch.delenv("GOENV_GEN_PACE_NS", raising=False)
+    env = goenv.GoEnv(n, seed=seed, max_ply=max_ply)
+    return env
+
+
+def rings(env, T, what, augs):
+    dev, n = env.device, env.n
+    feat = torch.full((T, n, 25, 19, 19), -2.0, device=dev) if "f" in what else None
+    legal = torch.full((T, n, 361), 5, dtype=torch.uint8, device=dev) if "l" in what else None
+    acts = torch.full((T, n), -7, dtype=torch.int32, device=dev) if "a" in what else None
+    return feat, legal, acts
+
+
+def same(x, y):
+    if x is None:
+        return y is None
+    if x.dtype == torch.float32:
+        x, y = x.view(torch.int32), y.view(torch.int32)
+    elif x.dtype == torch.uint16:
+        x, y = x.view(torch.int16), y.view(torch.int16)
+    return torch.equal(x, y)
+
+
+@pytest.mark.parametrize("n,T,what,aug", [(64, 1, "fla", False), (37, 2, "fla", True), (100, 3, "fl", True),
+                                          (96, 5, "la", False), (50, 9, "a", False), (130, 11, "f", True),
+                                          (300, 23, "fla", True)])
+def test_pipelined_equals_two_wave_kernel(goenv, monkeypatch, n, T, what, aug):
+    out = []
+    for pipe in (False, True):
+        env = make(goenv, monkeypatch, pipe, n, seed=5)
+        augs = ((torch.arange(n, dtype=torch.int32, device=env.device) * 3) % 8).contiguous() if aug else None
+        got = []
+        for _ in range(6):                              # launches follow one another: games end and restart inside
+            r = rings(env, T, what, augs)
+            env.generate(T, *r, aug_codes=augs)
+            torch.cuda.synchronize()
+            got += list(r)
+        got += [v for _, v in sorted(env.get_state().items())]
+        got.append(torch.tensor(env.stats()))
+        out.append(got)
+        env.close()
+    for i, (x, y) in enumerate(zip(*out)):
+        assert same(x, y), (i, n, T, what)
+    assert int(out[0][-1][goenv.ST_GAMES]) > 0 or T * 6 < 80
+
+
+def test_pipelined_rings_against_the_oracle(goenv, monkeypatch):
+    n, T, seed = 40, 30, 77
+    env = make(goenv, monkeypatch, True, n, seed, max_ply=70, pace=3000)
+    dev = env.device
+    augs = (torch.arange(n, dtype=torch.int32, device=dev) % 8).contiguous()
+    oracles = [OracleBoard() for _ in range(n)]
+    ended = 0
+    for launch in range(4):
+        feat, legal, acts = rings(env, T, "fla", augs)
+        env.generate(T, feat, legal, acts, aug_codes=augs)
+        f, lg, ac = feat.cpu().numpy(), legal.cpu().numpy(), acts.cpu().numpy()
+        for b in range(n):
+            o = oracles[b]
+            for t in range(T):
+                if o.is_game_end() or o.canonical()["scalars"][0] > 70:     # the device restarts it before this ply
+                    o = oracles[b] = OracleBoard()
+                    ended += 1
+                assert o.forward(int(ac[t, b]))[0], (launch, t, b)
+                assert np.array_equal(lg[t, b], o.legal()), (launch, t, b)
+                assert_planes_equal(f[t, b], o.extract(b % 8), "launch %d ply %d board %d" % (launch, t, b))
+    assert ended >= n
+    env.close()
+
+
+def test_preset_planes_and_graph_capture(goenv, monkeypatch):
+    """The constant planes preset (the eleven planes are the caller's) through the pipelined kernel, and a launch
+    recorded into a HIP graph: the replays continue the games exactly as plain calls do."""
+    n, T, seed = 128, 8, 9
+    plain = make(goenv, monkeypatch, True, n, seed)
+    graphed = make(goenv, monkeypatch, True, n, seed)
+    for e in (plain, graphed):
+        e.set_constant_planes_preset(True)
+    dev = plain.device
+    rp, rg = rings(plain, T, "fla", None), rings(graphed, T, "fla", None)
+    for r in (rp, rg):
+        r[0].zero_()
+        r[0][:, :, 12] = 3.5                               # a sentinel in a constant plane must survive
+    plain.generate(T, *rp)
+    graphed.generate(T, *rg)                               # one call outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        graphed.generate(T, *rg)
+    for _ in range(5):
+        plain.generate(T, *rp)
+        g.replay()
+        torch.cuda.synchronize()
+        for x, y in zip(rp, rg):
+            assert same(x, y)
+        assert float(rg[0][:, :, 12].min()) == 3.5 and float(rg[0][:, :, 16:].abs().max()) == 0.0
+    sp, sg = plain.get_state(), graphed.get_state()
+    for k in sp:
+        assert same(sp[k], sg[k]), k
+    plain.close()
+    graphed.close()
+
+
+def test_rate_limiter_tunes_itself_and_changes_no_byte(goenv, monkeypatch):
+    """Default settings at a size where the limiter matters: forty launches, during which the tuner walks through its
+    candidate paces; every ring equals the two-wave kernel's, and the tuner reports a pace and its estimates."""
+    n, T, seed = 1024, 16, 3
+    monkeypatch.delenv("GOENV_GEN_PIPE", raising=False)
+    monkeypatch.delenv("GOENV_GEN_PACE_NS", raising=False)
+    tuned = goenv.GoEnv(n, seed=seed, max_ply=722)
+    ref = make(goenv, monkeypatch, False, n, seed, max_ply=722)
+    rt, rr = rings(tuned, T, "fla", None), rings(ref, T, "fla", None)
+    for launch in range(40):
+        tuned.generate(T, *rt)
+        ref.generate(T, *rr)
+        if launch % 5 == 4:
+            torch.cuda.synchronize()
+            for x, y in zip(rt, rr):
+                assert same(x, y), launch
+    torch.cuda.synchronize()
+    pace, est = tuned.generate_pace()
+    assert 6.0 <= pace <= 7.5, pace
+    assert sum(1 for e in est if e > 0) >= 5, est
+    assert ref.generate_pace()[0] == 0.0
+    tuned.close()
+    ref.close()

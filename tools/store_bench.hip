@@ -8,7 +8,7 @@
 //   mode 2  board <-> workgroup maps (identity, XCD-contiguous, CU-contiguous, shuffled)
 //   mode 3  plane splits between two waves of a board      mode 4  one storing wave per group of boards
 //   mode 5  stream expanders from packed samples           mode 6  alignment of the wave-stores
-//   mode 7  cache-policy bits of the stores (sc0 / sc1 / nt)
+//   mode 7  cache-policy bits of the stores (sc0 / sc1 / nt)     mode 8  samples written in address order in time
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -591,6 +591,64 @@ static void run_pol(float* out, int n, int T, int reps) {
            ms * 1e3 / T, (double)n * T * FB * 4 / (ms * 1e-3) / 1e9);
   }
 }
+// mode 8: does the memory side take the same bytes faster when the boards' samples are written IN ADDRESS ORDER IN TIME?
+// One wave per board, persistent; board b starts its ply-t sample at T0 + t P + phase(b) P (100-MHz wall clock, common to
+// the chip), so that with phase(b) = b / n the samples being written at any instant are a narrow, contiguous, moving window
+// of the slot -- a write front made of whole samples.  phase mode 0: free-running (no clock); 1: b / n; 2: all boards at once;
+// 3: hashed.  Reported: the time per ply actually achieved (>= P when paced).
+__global__ __launch_bounds__(64) void p_persist_stagger(float* out, int n, int T, int map, int phase, int period_ns,
+                                                        unsigned long long* t0p) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  int b = w;
+  if (map == 1) b = (w & 7) * (n >> 3) + (w >> 3);
+  unsigned long long t0 = 0;
+  long long off_ns = 0;
+  if (phase) {
+    const unsigned long long now = wall_clock64();
+    if (lane == 0) atomicMin(t0p, now);
+    __builtin_amdgcn_s_sleep(127);
+    t0 = __hip_atomic_load(t0p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 3000;   // 30 us after the first wave started
+    t0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(t0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)t0);
+    if (phase == 1) off_ns = (long long)b * period_ns / n;
+    else if (phase == 3) off_ns = (long long)(((unsigned)b * 40503u) % (unsigned)n) * period_ns / n;
+  }
+  for (int t = 0; t < T; ++t) {
+    if (phase) {
+      const unsigned long long target = t0 + (unsigned long long)(((long long)t * period_ns + off_ns) / 10);
+      for (int spin = 0; spin < (1 << 20) && wall_clock64() < target; ++spin) __builtin_amdgcn_s_sleep(1);
+    }
+    float* o = out + ((size_t)t * n + b) * FB;
+    for (int pl = 0; pl < 25; ++pl) {
+      float v = (float)(pl + t);
+      uf4 val = {v, v + 1, v + 2, v + 3};
+      *(uf4*)(o + pl * NP + 4 * lane) = val;
+      if (lane < 26) *(uf4*)(o + pl * NP + 256 + 4 * lane) = val;
+      if (lane == 26) o[pl * NP + 360] = v;
+    }
+  }
+}
+static void run_stagger(float* out, int n, int T, int reps) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  unsigned long long* t0p; hipMalloc(&t0p, 8);
+  const int periods[6] = {5000, 5500, 6000, 6500, 7000, 8000};
+  for (int map = 0; map < 2; ++map)
+    for (int phase = 0; phase < 4; ++phase)
+      for (int pi = 0; pi < (phase ? 6 : 1); ++pi) {
+        float tot = 0;
+        for (int r = 0; r < reps + 1; ++r) {
+          hipMemsetAsync(t0p, 0xff, 8, 0);
+          hipEventRecord(e0);
+          hipLaunchKernelGGL(p_persist_stagger, dim3(n), dim3(64), 0, 0, out, n, T, map, phase, periods[pi], t0p);
+          hipEventRecord(e1); hipEventSynchronize(e1);
+          float ms; hipEventElapsedTime(&ms, e0, e1);
+          if (r) tot += ms;
+        }
+        float ms = tot / reps - (phase ? 0.030f : 0.f);   // the 30-us lead-in of the paced variants
+        printf("n=%d T=%d map %d phase %d period %4d ns  %8.3f us per ply  %7.1f GB/s\n", n, T, map, phase, phase ? periods[pi] : 0,
+               ms * 1e3 / T, (double)n * T * FB * 4 / (ms * 1e-3) / 1e9);
+        fflush(stdout);
+      }
+}
 static void run_front(float* out, int n, int T, int reps) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int nbp = n * T;
@@ -627,6 +685,7 @@ int main(int argc, char** argv) {
   const int front = argc > 4 ? atoi(argv[4]) : 0; // 1: the two-stage (expander) probes over n*T board-plies
   float* out;
   if (hipMalloc(&out, (size_t)n * (T > 0 ? T : 1) * FB * 4 + 64) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+  if (front == 8) { run_stagger(out, n, T, reps); return 0; }
   if (front == 7) { run_pol(out, n, T, reps); return 0; }
   if (front == 6) { run_flat(out, n, T, reps); return 0; }
   if (front == 5) { run_expand_stream(out, n, T, reps); return 0; }
