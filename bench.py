@@ -8,7 +8,7 @@ restarted in place (as ELF's selfplay restarts games, go/game.cc:81-90), so ever
 one move on every board.
 
 A STEP is one pass of the timed kernel over one batch of output: ONE launch of the persistent
-generator (goenv_generate, kernel k_generate), which plays `plies_per_step` plies (default 64, the
+generator (goenv_generate, kernel k_generate_pipe), which plays `plies_per_step` plies (default 64, the
 ring depth) of every board with the boards kept in LDS/registers and writes ply t's planes, mask and
 move to slot t of ring buffers -- nothing is skipped against a launch per ply (same bytes, same
 order; tests/test_gpu_entry_points.py holds the two paths bit-identical).  So
@@ -234,6 +234,8 @@ def main():
     elapsed, kernel_ms = regions[len(regions) // 2]
     kernel_ms = sorted(r[1] for r in regions)[len(regions) // 2]
 
+    gen_kernel = env.generate_kernel()
+    gen_pace, gen_est = env.generate_pace()
     # end-of-episode statistics: count the games still in flight, then the one collective
     env.finish()
     stats = reduce_stats(env.stats_tensor()).cpu().tolist()
@@ -259,14 +261,17 @@ def main():
                    "collective_backend": backend if dist_on else None,
                    "preroll_plies": args.preroll, "warmup_steps_run": warm_steps, "reps": len(regions),
                    "region_ms": [round(r[0] * 1e3, 4) for r in regions], "reported": "median region"},
-        "roofline": {"bound": "hbm", "kernel": "k_generate", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": gen_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "frac_wall": alg_launch * launches / elapsed / 1e9 / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_unit": "bytes per launch, from %s (rocprofv3 PMC passes of this "
                                                          "command; not measured in this run)" % traffic_src,
                      "algorithmic_bytes_per_launch": alg_launch,
                      "bytes_per_board_ply": ALG_BYTES_PER_BOARD_PLY, "record_bytes_per_board_launch": 2 * REC_BYTES,
-                     "kernel_ms": kernel_ms},
+                     "kernel_ms": kernel_ms,
+                     # the generator's rate limiter tunes itself (include/goenv.h, goenv_generate_pace): the pace it
+                     # settled on (ns offered per board-ply) and its time estimates (us per ply) per candidate pace
+                     "store_pace_ns_per_board_ply": gen_pace, "pace_estimates_us_per_ply": [round(e, 3) for e in gen_est]},
         "feature_extract_GBps": achieved,
         "stats": {"games": stats[0], "black_wins": stats[1], "white_wins": stats[2], "plies": stats[4],
                   "max_len": stats[9], "ply_cap_hits": stats[8]},

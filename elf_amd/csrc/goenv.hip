@@ -786,7 +786,9 @@ __global__ __launch_bounds__(128) void k_generate_pipe(PlyParams P, int n_plies,
       const int q = i < 4 ? 4 * lane + i : (lane < 26 ? 256 + 4 * lane : NPTS - 4) + (i - 4);
       src[i] = aug ? d4_src(aug, q) : q;
     }
-    unsigned long long next = 0;
+    // the schedule starts when the wave does, not with its first sample (which comes a ply later): the first two samples
+    // go out back to back, into a memory system that the launch has not loaded yet
+    unsigned long long next = wall_clock64();
     for (int t = 0; t < n_plies; ++t) {
       PTICK(0);
       pipe_wait(&X.produced, t + 1);
@@ -1131,9 +1133,9 @@ __global__ __launch_bounds__(64) void k_tactics(const BoardRec* state, int n_tot
 // with a neighbour tried now and then.  The pace changes WHEN samples are written, never what is written.
 struct GenTune {
   static constexpr int NC = 6, NPEND = 8;
-  // ns per board-ply offered: 36,465 B / 6.65 ns = 5.48 TB/s is the safe side of every cliff seen
-  static constexpr float cand[NC] = {6.05f, 6.25f, 6.45f, 6.65f, 6.90f, 7.30f};
-  static constexpr int SAFE = 3;
+  // ns per board-ply offered: 36,465 B / 6.75 ns = 5.40 TB/s is the safe side of every cliff seen
+  static constexpr float cand[NC] = {6.10f, 6.25f, 6.40f, 6.55f, 6.75f, 7.10f};
+  static constexpr int SAFE = 4;
   float est[NC];          // us per ply, running estimate (0: none yet)
   int samples[NC], launched[NC];
   int launches;
@@ -1175,6 +1177,7 @@ struct goenv_ctx {
   int gen_pace_ns;                     // its rate limiter, ns between two samples of a board: -1 = tuned (default),
                                        // else pinned, 0 = none (GOENV_GEN_PACE_NS)
   int gen_resident;                    // boards of k_generate_pipe that the device holds at once (0: not asked yet)
+  int gen_last_pipe;                   // the last goenv_generate went through k_generate_pipe
   GenTune tune;
 };
 
@@ -1988,6 +1991,7 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
   }
   const bool resident = c->n <= c->gen_resident;
   const bool pipe = c->nw ? false : (c->gen_pipe < 0 ? resident : c->gen_pipe != 0);
+  c->gen_last_pipe = pipe ? 1 : 0;
   if (!pipe) {
     const int nw = c->nw ? c->nw : (c->n <= 4096 ? 2 : 3);
     GO_LAUNCH(nw, k_generate, c->n, S(stream), P, n_plies, actions_ring);
@@ -2034,9 +2038,11 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
 }
 
 // What the generator's self-tuning rate limiter has settled on: ns per board-ply offered (0: not in use or no result
-// yet), and its estimates per candidate in est_out[6] (us per ply, 0 = none).  Diagnostic.
-int goenv_generate_pace(goenv_ctx* c, float* pace_ns_per_board_out, float* est_out) {
+// yet), its estimates per candidate in est_out[6] (us per ply, 0 = none), and whether the last goenv_generate went through
+// the pipelined kernel.  Diagnostic.
+int goenv_generate_pace(goenv_ctx* c, float* pace_ns_per_board_out, float* est_out, int* pipelined_out) {
   if (!c) return fail("goenv_generate_pace: ctx is NULL");
+  if (pipelined_out) *pipelined_out = c->gen_last_pipe;
   GenTune& t = c->tune;
   if (t.events_ready) gen_tune_collect(t);
   int best = -1;

@@ -78,7 +78,7 @@ _SIGS = {
     "goenv_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "goenv_playout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "goenv_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "goenv_generate_pace": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "goenv_generate_pace": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "goenv_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goenv_fast_score": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "goenv_topk_policy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
@@ -425,8 +425,14 @@ class GoEnv:
         """goenv_generate_pace: (ns per board-ply that the generator's rate limiter has settled on, [us per ply per
         candidate pace])."""
         pace, est = C.c_float(0), (C.c_float * 6)()
-        self._chk(self.lib.goenv_generate_pace(self._h, C.byref(pace), est))
+        self._chk(self.lib.goenv_generate_pace(self._h, C.byref(pace), est, None))
         return pace.value, list(est)
+
+    def generate_kernel(self):
+        """Name of the kernel that the last generate() of this context launched."""
+        pipe = C.c_int(0)
+        self._chk(self.lib.goenv_generate_pace(self._h, None, None, C.byref(pipe)))
+        return "k_generate_pipe" if pipe.value else "k_generate"
 
     def score(self, score_out=None, fast_out=None):
         self._check(score_out, torch.float32, (self.n,), "score_out")

@@ -42,3 +42,11 @@ for w, nm in enumerate(("rules wave", "feature wave")):
         nm, m[:5].sum().item(), tot.min().item(), tot.quantile(0.1).item(), tot.median().item(), tot.quantile(0.9).item(), tot.max().item()))
     for i in range(5):
         print("    %-45s %7.0f" % (names[w][i], m[i].item()))
+
+ftot = acc[:, 1, :5].sum(1)
+print("  feature wave total by XCD (workgroup %% 8): %s" % " ".join("%.0f" % ftot[x::8].mean().item() for x in range(8)))
+print("  feature wave total by dispatch order within the XCD (workgroup // 8, groups of 16): %s" % " ".join(
+    "%.0f" % ftot.view(-1, 8)[i:i + 16].mean().item() for i in range(0, B // 8, 16)))
+rt = acc[:, 0, 1]
+print("  rules time per ply by board: min %.0f median %.0f max %.0f; correlation of a board's rules time with its feature-wave total: %.2f" % (
+    rt.min().item(), rt.median().item(), rt.max().item(), torch.corrcoef(torch.stack([rt, ftot]))[0, 1].item()))
