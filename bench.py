@@ -8,7 +8,7 @@ restarted in place (as ELF's selfplay restarts games, go/game.cc:81-90), so ever
 one move on every board.
 
 A STEP is one pass of the timed kernel over one batch of output: ONE launch of the persistent
-generator (goenv_generate, kernel k_generate_pipe), which plays `plies_per_step` plies (default 64, the
+generator (goenv_generate, kernel k_generate_pipe), which plays `plies_per_step` plies (default 128, the
 ring depth) of every board with the boards kept in LDS/registers and writes ply t's planes, mask and
 move to slot t of ring buffers -- nothing is skipped against a launch per ply (same bytes, same
 order; tests/test_gpu_entry_points.py holds the two paths bit-identical).  So
@@ -138,7 +138,9 @@ def main():
     ap.add_argument("--steps", type=int, default=32, help="timed generator launches (one step = --ring plies of every board)")
     ap.add_argument("--warmup", type=int, default=4, help="untimed launches of the same shape before the timed region")
     ap.add_argument("--boards", type=int, default=1024, help="boards per GPU (cfg 2: 1024; cfg 4 shard: 8192)")
-    ap.add_argument("--ring", type=int, default=64, help="ring depth in plies = plies per step (per generator launch)")
+    ap.add_argument("--ring", type=int, default=128,
+                    help="ring depth in plies = plies per step (per generator launch); 4.8 GB of planes at 1,024 boards "
+                         "(64 until round 3: a launch boundary costs the pipelined generator about 28 us)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--preroll", type=int, default=4096,
                     help="plies every board is rolled forward without outputs before the warmup (set-up: steady state)")
