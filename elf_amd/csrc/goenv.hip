@@ -1094,23 +1094,26 @@ __global__ __launch_bounds__(64) void k_tactics(const BoardRec* state, int n_tot
 }
 
 // Launch of a kernel template on the waves-per-board count chosen for this call.
-#define GO_LAUNCH(NWSEL, KERNEL, GRID, STREAM, ...)                                                  \
+// probe (tuning only): GOENV_LDS_PAD=<bytes> of unused dynamic LDS per workgroup, to cap the workgroups a CU holds
+static size_t g_lds_pad = getenv("GOENV_LDS_PAD") ? (size_t)atoi(getenv("GOENV_LDS_PAD")) : 0;
+#define GO_LAUNCH_LDS(NWSEL, KERNEL, GRID, LDS, STREAM, ...)                                           \
   do {                                                                                               \
     switch (NWSEL) {                                                                                 \
-      case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(GRID), dim3(128), 0, STREAM, __VA_ARGS__); break; \
-      case 3: hipLaunchKernelGGL((KERNEL<3>), dim3(GRID), dim3(192), 0, STREAM, __VA_ARGS__); break; \
-      case 6: hipLaunchKernelGGL((KERNEL<6>), dim3(GRID), dim3(384), 0, STREAM, __VA_ARGS__); break; \
-      default: hipLaunchKernelGGL((KERNEL<1>), dim3(GRID), dim3(64), 0, STREAM, __VA_ARGS__); break; \
+      case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(GRID), dim3(128), LDS, STREAM, __VA_ARGS__); break; \
+      case 3: hipLaunchKernelGGL((KERNEL<3>), dim3(GRID), dim3(192), LDS, STREAM, __VA_ARGS__); break; \
+      case 6: hipLaunchKernelGGL((KERNEL<6>), dim3(GRID), dim3(384), LDS, STREAM, __VA_ARGS__); break; \
+      default: hipLaunchKernelGGL((KERNEL<1>), dim3(GRID), dim3(64), LDS, STREAM, __VA_ARGS__); break; \
     }                                                                                                \
   } while (0)
+#define GO_LAUNCH(NWSEL, KERNEL, GRID, STREAM, ...) GO_LAUNCH_LDS(NWSEL, KERNEL, GRID, g_lds_pad, STREAM, __VA_ARGS__)
 
 #define GO_LAUNCH_PLY_MODE(NWSEL, MODE, GRID, STREAM, P)                                              \
   do {                                                                                                \
     switch (NWSEL) {                                                                                  \
-      case 2: hipLaunchKernelGGL((k_ply<2, MODE>), dim3(GRID), dim3(128), 0, STREAM, P); break;       \
-      case 3: hipLaunchKernelGGL((k_ply<3, MODE>), dim3(GRID), dim3(192), 0, STREAM, P); break;       \
-      case 6: hipLaunchKernelGGL((k_ply<6, MODE>), dim3(GRID), dim3(384), 0, STREAM, P); break;       \
-      default: hipLaunchKernelGGL((k_ply<1, MODE>), dim3(GRID), dim3(64), 0, STREAM, P); break;       \
+      case 2: hipLaunchKernelGGL((k_ply<2, MODE>), dim3(GRID), dim3(128), g_lds_pad, STREAM, P); break;       \
+      case 3: hipLaunchKernelGGL((k_ply<3, MODE>), dim3(GRID), dim3(192), g_lds_pad, STREAM, P); break;       \
+      case 6: hipLaunchKernelGGL((k_ply<6, MODE>), dim3(GRID), dim3(384), g_lds_pad, STREAM, P); break;       \
+      default: hipLaunchKernelGGL((k_ply<1, MODE>), dim3(GRID), dim3(64), g_lds_pad, STREAM, P); break;       \
     }                                                                                                 \
   } while (0)
 
@@ -1588,8 +1591,13 @@ int goenv_collect_sel(goenv_ctx* c, const int32_t* idx, int first, int count, co
   goenv_sample_out m;
   memset(&m, 0, sizeof(m));
   if (meta) m = *meta;
-  GO_LAUNCH(pick_nw_features(c, count), k_features, count, S(stream), c->state, c->n, idx, first, count, aug_codes, c->lut,
-            feat_out, legal_out, m, meta ? 1 : 0, c->lut1, pick_zero_first(c, count), c->xcd_map);
+  // From 16,384 rows on a launch of free-running workgroups offers the memory side more stores than it takes well: 16,000 B
+  // of unused LDS per workgroup hold a CU at 7 boards instead of 10 (65,536 boards: 460 -> 443 us, 32,768: 231 -> 225,
+  // 16,384: 118 -> 116; profiles/r03_occupancy_cap_probe.txt).  The ply kernel loses from the same cap and keeps none.
+  const int nw = pick_nw_features(c, count);
+  const size_t lds_pad = g_lds_pad ? g_lds_pad : ((count >= 16384 && nw == 3 && feat_out) ? 16000 : 0);
+  GO_LAUNCH_LDS(nw, k_features, count, lds_pad, S(stream), c->state, c->n, idx, first, count, aug_codes, c->lut,
+                feat_out, legal_out, m, meta ? 1 : 0, c->lut1, pick_zero_first(c, count), c->xcd_map);
   HIPCHK(hipGetLastError());
   return 0;
 }
