@@ -9,6 +9,7 @@
 //   mode 3  plane splits between two waves of a board      mode 4  one storing wave per group of boards
 //   mode 5  stream expanders from packed samples           mode 6  alignment of the wave-stores
 //   mode 7  cache-policy bits of the stores (sc0 / sc1 / nt)     mode 8  samples written in address order in time
+//   mode 9  paced stores: rows per XCD / per CU / ring[b][t] / half samples / two waves
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -649,6 +650,63 @@ static void run_stagger(float* out, int n, int T, int reps) {
         fflush(stdout);
       }
 }
+// mode 9: paced stores (mode 8, hashed phases), which pattern does the memory side take fastest when it is NOT overdriven?
+// var 0: rows per XCD (the product)   1: CU-contiguous rows   2: ring[b][t] instead of ring[t][b]
+// var 3: a sample in two halves, each at half the period   4: two waves per board, a contiguous half each
+// var 5: board = workgroup (rows interleaved over the XCDs)
+__global__ __launch_bounds__(128) void p_paced(float* out, int n, int T, int var, int period_ns, unsigned long long* t0p) {
+  const int w = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (var != 4 && wave) return;
+  int b = (w & 7) * (n >> 3) + (w >> 3);
+  if (var == 1) { const int cu = w & 255, k = w >> 8; b = cu * (n >> 8) + k; }
+  if (var == 5) b = w;
+  const unsigned long long now = wall_clock64();
+  if (lane == 0) atomicMin(t0p, now);
+  __builtin_amdgcn_s_sleep(127);
+  unsigned long long t0 = __hip_atomic_load(t0p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 3000;
+  t0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(t0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)t0);
+  const long long off_ns = (long long)(((unsigned)b * 40503u) % (unsigned)n) * period_ns / n;
+  const int halves = var == 3 ? 2 : 1;
+  for (int t = 0; t < T; ++t) {
+    float* o = out + (var == 2 ? ((size_t)b * T + t) : ((size_t)t * n + b)) * FB;
+    for (int h = 0; h < halves; ++h) {
+      const unsigned long long target = t0 + (unsigned long long)(((long long)t * period_ns + off_ns + (long long)h * period_ns / 2) / 10);
+      for (int spin = 0; spin < (1 << 20) && wall_clock64() < target; ++spin) __builtin_amdgcn_s_sleep(1);
+      int p0 = 0, p1 = 25;
+      if (var == 3) { p0 = h ? 13 : 0; p1 = h ? 25 : 13; }
+      if (var == 4) { p0 = wave ? 13 : 0; p1 = wave ? 25 : 13; }
+      for (int pl = p0; pl < p1; ++pl) {
+        float v = (float)(pl + t);
+        uf4 val = {v, v + 1, v + 2, v + 3};
+        *(uf4*)(o + pl * NP + 4 * lane) = val;
+        if (lane < 26) *(uf4*)(o + pl * NP + 256 + 4 * lane) = val;
+        if (lane == 26) o[pl * NP + 360] = v;
+      }
+    }
+  }
+}
+static void run_paced(float* out, int n, int T, int reps) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  unsigned long long* t0p; hipMalloc(&t0p, 8);
+  const int periods[7] = {5600, 5800, 5900, 6000, 6100, 6200, 6400};
+  for (int var = 0; var < 6; ++var)
+    for (int pi = 0; pi < 7; ++pi) {
+      const int period = (int)((long long)periods[pi] * n / 1024);
+      float tot = 0;
+      for (int r = 0; r < reps + 1; ++r) {
+        hipMemsetAsync(t0p, 0xff, 8, 0);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(p_paced, dim3(n), dim3(128), 0, 0, out, n, T, var, period, t0p);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (r) tot += ms;
+      }
+      float ms = tot / reps - 0.030f;
+      printf("n=%d T=%d var %d period %5d ns  %8.3f us per ply  %7.1f GB/s\n", n, T, var, period, ms * 1e3 / T,
+             (double)n * T * FB * 4 / (ms * 1e-3) / 1e9);
+      fflush(stdout);
+    }
+}
 static void run_front(float* out, int n, int T, int reps) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int nbp = n * T;
@@ -685,6 +743,7 @@ int main(int argc, char** argv) {
   const int front = argc > 4 ? atoi(argv[4]) : 0; // 1: the two-stage (expander) probes over n*T board-plies
   float* out;
   if (hipMalloc(&out, (size_t)n * (T > 0 ? T : 1) * FB * 4 + 64) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+  if (front == 9) { run_paced(out, n, T, reps); return 0; }
   if (front == 8) { run_stagger(out, n, T, reps); return 0; }
   if (front == 7) { run_pol(out, n, T, reps); return 0; }
   if (front == 6) { run_flat(out, n, T, reps); return 0; }
