@@ -837,6 +837,119 @@ __global__ __launch_bounds__(128) void k_generate_pipe(PlyParams P, int n_plies,
 #undef PTICK
 }
 
+// The pipelined generator for MORE boards than the device holds workgroups: a grid of resident workgroups, each with the
+// boards w, w + G, w + 2G, ... waiting in LDS in the record's own layout (dynamic LDS: 1,632 B per board).  The rules wave
+// takes them in turn, one ply each; the feature wave writes their samples at an even pace.  Same rings as k_generate.
+__global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_plies, int32_t* actions_ring,
+                                                             int ply_period_ticks) {
+  __shared__ BoardLds<1> L;
+  __shared__ PipeLds X;
+  extern __shared__ __align__(16) unsigned char saved_raw[];
+  BoardRec* saved = reinterpret_cast<BoardRec*>(saved_raw);
+  const int G = (int)gridDim.x, w = (int)blockIdx.x, n = P.n;
+  const int mine = w < n ? (n - 1 - w) / G + 1 : 0;          // boards of this workgroup
+  // its i-th board: turn i of the grid covers the rows [i G, (i + 1) G) of a slot -- one window of the output at a time, each XCD
+  // a contiguous part of it (GOENV_MULTI_ROWS=1, probe: the rows w + i G dealt per XCD over the whole slot instead)
+  auto board_at = [&](int i) {
+#ifdef GOENV_MULTI_ROWS
+    return xcd_row(w + i * G, n, P.xcd_map);
+#else
+    const int left = n - i * G;
+    return i * G + xcd_row(w, left < G ? left : G, P.xcd_map);
+#endif
+  };
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63);
+  if (threadIdx.x == 0) { X.produced = 0; X.consumed = 0; }
+  for (int i = threadIdx.x; i < PIPE_LUT_N; i += 128) X.lut[i] = P.lut[i];
+  constexpr int REC_VEC = (int)(sizeof(BoardRec) / 16);
+  for (int i = 0; i < mine; ++i) {
+    const uint4* src = reinterpret_cast<const uint4*>(P.state + board_at(i));
+    uint4* dst = reinterpret_cast<uint4*>(saved + i);
+    for (int v = threadIdx.x; v < REC_VEC; v += 128) dst[v] = src[v];
+  }
+  __syncthreads();   // the only barrier of the kernel
+  const int items = mine * n_plies;
+  if (wave == 0) {
+    Geo<1> g;
+    geo_init(g);
+    fill_rim(L, g.tid);
+    wsync<1>();
+    int j = 0;
+    for (int t = 0; t < n_plies; ++t) {      // host-supplied bounds, the same for both waves
+      for (int i = 0; i < mine; ++i, ++j) {
+        const int b = board_at(i);
+        Scalars s;
+        uint32_t lab[NWORDS], lastp[NWORDS];
+        Masks m;
+        Own<1> o;
+        lds_load_board(saved[i], L, g, lab, lastp, s, m);
+        own_from_masks(g, m, o);
+        if (s.done) {
+          if (!s.counted) account_game(P.stats, g.tid, s, tromp_taylor(L, g, lab), P.komi);
+          restart_in_place(L, g, lab, lastp, s, m, o);
+        }
+        const int a = ply_body<1, true>(L, g, lab, lastp, s, m, o, P, b, 0ll);
+        gather_masks(L, g, o, m);
+        lds_store_board(saved[i], g, lab, lastp, s, m);
+        if (j >= PIPE_DEPTH) pipe_wait(&X.consumed, j - PIPE_DEPTH + 1);
+        PipeSnap& S = X.snap[j % PIPE_DEPTH];
+        snapshot_write(S, g, lab, lastp, s, o, a);
+        if (g.lane == 0) { S.aug = P.aug ? (P.aug[b] & 7) : 0; S.row = b; }
+        pipe_post(&X.produced, j + 1, g.lane);
+      }
+    }
+    wsync<1>();
+    for (int i = 0; i < mine; ++i) {
+      uint4* dst = reinterpret_cast<uint4*>(P.state + board_at(i));
+      const uint4* src = reinterpret_cast<const uint4*>(saved + i);
+      for (int v = lane; v < REC_VEC; v += 64) dst[v] = src[v];
+    }
+  } else {
+    const int period = mine > 0 ? ply_period_ticks / mine : 0;
+    int src[8], cur_aug = -1;
+    unsigned long long next = wall_clock64();
+    int t = 0, i = 0;
+    for (int j = 0; j < items; ++j) {
+      pipe_wait(&X.produced, j + 1);
+      const PipeSnap& S = X.snap[j % PIPE_DEPTH];
+      const int aug = __builtin_amdgcn_readfirstlane(S.aug), b = __builtin_amdgcn_readfirstlane(S.row);
+      if (aug != cur_aug) {
+        for (int q8 = 0; q8 < 8; ++q8) {
+          const int q = q8 < 4 ? 4 * lane + q8 : (lane < 26 ? 256 + 4 * lane : NPTS - 4) + (q8 - 4);
+          src[q8] = aug ? d4_src(aug, q) : q;
+        }
+        cur_aug = aug;
+      }
+      SnapRegs r;
+      snapshot_load(S, lane, src, r);
+      pipe_post(&X.consumed, j + 1, lane);
+      if (period) {   // the rate limiter of k_generate_pipe, one sample per period
+        unsigned long long now = wall_clock64();
+        for (int spin = 0; spin < 4096 && now < next; ++spin) {   // bounded: a wave always gets out
+          __builtin_amdgcn_s_sleep(1);
+          now = wall_clock64();
+        }
+        next = (now > next + 2ull * (unsigned long long)period) ? now + (unsigned long long)period
+                                                                 : next + (unsigned long long)period;
+      }
+      const size_t row = (size_t)t * n + b;
+      if (actions_ring && lane == 0) actions_ring[row] = r.action;
+      uint8_t* lg = P.legal ? P.legal + row * NPTS : nullptr;
+      if (P.feat) {
+        if (P.zero_first & 4) snapshot_expand<false>(r, X, lane, aug, src, P.feat + row * GOENV_FEAT_FLOATS, lg);
+        else snapshot_expand<true>(r, X, lane, aug, src, P.feat + row * GOENV_FEAT_FLOATS, lg);
+      } else if (lg) {
+        for (int k = 0; k < NWORDS; ++k) {
+          const int p = lane + 64 * k;
+          if (p < NPTS) lg[p] = (uint8_t)((r.lg[k] >> lane) & 1ull);
+        }
+      }
+      if (++i == mine) { i = 0; ++t; }
+    }
+  }
+}
+
 // Replay of given move lists (SGF records packed on the host): row b applies
 // moves[b*stride + 0 .. nmoves[b]) to its board with GoState::forward semantics and stops at the
 // first illegal move (go/offpolicy_loader.cc:120-126); napplied[b] = moves applied.  The board
@@ -1180,7 +1293,8 @@ struct goenv_ctx {
   int gen_pace_ns;                     // its rate limiter, ns between two samples of a board: -1 = tuned (default),
                                        // else pinned, 0 = none (GOENV_GEN_PACE_NS)
   int gen_resident;                    // boards of k_generate_pipe that the device holds at once (0: not asked yet)
-  int gen_last_pipe;                   // the last goenv_generate went through k_generate_pipe
+  int gen_last_pipe;                   // the last goenv_generate went through k_generate_pipe (1) / _multi (2)
+  int gen_multi_m, gen_multi_grid;     // k_generate_pipe_multi: boards per workgroup (0: not asked yet, -1: none fits), grid
   GenTune tune;
 };
 
@@ -1998,8 +2112,20 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
     c->gen_resident = per_cu * cus > 0 ? per_cu * cus : -1;
   }
   const bool resident = c->n <= c->gen_resident;
-  const bool pipe = c->nw ? false : (c->gen_pipe < 0 ? resident : c->gen_pipe != 0);
-  c->gen_last_pipe = pipe ? 1 : 0;
+  // more boards than that: several boards per resident workgroup, waiting in LDS (k_generate_pipe_multi), up to 16 each
+  if (!resident && !c->gen_multi_m && c->gen_resident > 0) {
+    c->gen_multi_m = -1;
+    for (int m = 2; m <= 16 && c->gen_multi_m < 0; ++m) {
+      int per_cu = 0, cus = 0;
+      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_generate_pipe_multi, 128, (size_t)m * sizeof(BoardRec)));
+      HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+      const int grid = (((c->n + m - 1) / m + 7) / 8) * 8;
+      if (grid <= per_cu * cus) { c->gen_multi_m = m; c->gen_multi_grid = grid; }
+    }
+  }
+  const bool multi = !resident && c->gen_multi_m > 0 && !c->nw && c->gen_pipe != 0;
+  const bool pipe = c->nw ? false : (c->gen_pipe < 0 ? (resident || multi) : c->gen_pipe != 0);
+  c->gen_last_pipe = pipe ? (multi ? 2 : 1) : 0;
   if (!pipe) {
     const int nw = c->nw ? c->nw : (c->n <= 4096 ? 2 : 3);
     GO_LAUNCH(nw, k_generate, c->n, S(stream), P, n_plies, actions_ring);
@@ -2009,8 +2135,8 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
   int pace_ticks = 0;   // 10-ns ticks of the wall clock
   GenTune::Pend* timed = nullptr;
   if (c->gen_pace_ns >= 0) {
-    pace_ticks = resident ? c->gen_pace_ns / 10 : 0;
-  } else if (resident && P.feat) {
+    pace_ticks = (resident || multi) ? c->gen_pace_ns / 10 : 0;
+  } else if ((resident || multi) && P.feat) {
     GenTune& t = c->tune;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (stream) (void)hipStreamIsCapturing(S(stream), &cap);
@@ -2033,10 +2159,15 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
       for (int i = 0, best = -1; i < GenTune::NC; ++i)
         if (t.samples[i] && (best < 0 || t.est[i] < t.est[best])) cand = best = i;
     }
-    pace_ticks = (int)(GenTune::cand[cand] * (float)c->n / 10.f);
+    // with several boards per workgroup the cliff sits 8 % further up (measured: 6.8 ns per board-ply at 4,096 boards, 7.2 at 8,192)
+    pace_ticks = (int)(GenTune::cand[cand] * (multi ? 1.08f : 1.f) * (float)c->n / 10.f);
   }
   if (timed) HIPCHK(hipEventRecord(timed->e0, S(stream)));
-  hipLaunchKernelGGL(k_generate_pipe, dim3(c->n), dim3(128), 0, S(stream), P, n_plies, actions_ring, pace_ticks);
+  if (multi)   // pace_ticks: the time of one ply of ALL boards; a workgroup divides it by its boards
+    hipLaunchKernelGGL(k_generate_pipe_multi, dim3(c->gen_multi_grid), dim3(128), (size_t)c->gen_multi_m * sizeof(BoardRec),
+                       S(stream), P, n_plies, actions_ring, pace_ticks);
+  else
+    hipLaunchKernelGGL(k_generate_pipe, dim3(c->n), dim3(128), 0, S(stream), P, n_plies, actions_ring, pace_ticks);
   HIPCHK(hipGetLastError());
   if (timed) {
     HIPCHK(hipEventRecord(timed->e1, S(stream)));
@@ -2058,7 +2189,7 @@ int goenv_generate_pace(goenv_ctx* c, float* pace_ns_per_board_out, float* est_o
     if (est_out) est_out[i] = t.samples[i] ? t.est[i] : 0.f;
     if (t.samples[i] && (best < 0 || t.est[i] < t.est[best])) best = i;
   }
-  if (pace_ns_per_board_out) *pace_ns_per_board_out = best < 0 ? 0.f : GenTune::cand[best];
+  if (pace_ns_per_board_out) *pace_ns_per_board_out = best < 0 ? 0.f : GenTune::cand[best] * (c->gen_last_pipe == 2 ? 1.08f : 1.f);
   return 0;
 }
 

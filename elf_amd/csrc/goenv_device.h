@@ -991,6 +991,7 @@ struct __attribute__((aligned(16))) PipeSnap {
   uint32_t raw[TAB_N];                  // label (colour, liberty class) | last_placed << 16 of every point, board order
   unsigned long long legal[NWORDS];     // legal mask of the side to move
   int32_t ply, next, ko, action;        // ko = GetSimpleKoLocation or -1
+  int32_t aug, row, pad[2];             // k_generate_pipe_multi: the sample's D4 code and its row inside a ring slot
 };
 
 constexpr int PIPE_DEPTH = 4;           // snapshots in flight between the two waves
@@ -1057,6 +1058,40 @@ __device__ __forceinline__ void snapshot_load(const PipeSnap& S, int lane, const
     r.ww[k] = __ballot(col == 2);
   }
   r.wb[NWORDS] = 0; r.ww[NWORDS] = 0;
+}
+
+// A board that waits for its next turn in LDS (k_generate_pipe_multi: several boards per workgroup), in the record's own
+// layout.  One wave; the label image's rim is the caller's.
+__device__ __forceinline__ void lds_load_board(const BoardRec& R, BoardLds<1>& L, const Geo<1>& g, uint32_t lab[],
+                                               uint32_t lastp[], Scalars& s, Masks& m) {
+  GO_UNROLL
+  for (int k = 0; k < NWORDS; ++k) {
+    const bool v = g.p[k] < NPTS;
+    lab[k] = v ? R.lab[g.p[k]] : 0u;
+    lastp[k] = v ? R.lastp[g.p[k]] : 0u;
+    if (v) L.lab[g.c[k]] = (uint16_t)lab[k];
+  }
+  int sc[16];
+  GO_UNROLL
+  for (int i = 0; i < 16; ++i) sc[i] = __builtin_amdgcn_readfirstlane(R.sc[i]);
+  s.ply = sc[SC_PLY]; s.next = sc[SC_NEXT]; s.bcap = sc[SC_BCAP]; s.wcap = sc[SC_WCAP];
+  s.l1 = sc[SC_L1]; s.l2 = sc[SC_L2]; s.l3 = sc[SC_L3]; s.l4 = sc[SC_L4];
+  s.koage = sc[SC_KOAGE]; s.ko = sc[SC_KO]; s.kocolor = sc[SC_KOCOLOR];
+  s.done = sc[SC_DONE]; s.game = sc[SC_GAME]; s.counted = sc[SC_COUNTED]; s.seq = sc[SC_SEQ]; s.seqtot = sc[SC_SEQTOT];
+  GO_UNROLL
+  for (int j = 0; j < NWORDS; ++j) { m.legal[j] = uni64(R.legal[j]); m.cand[j] = uni64(R.cand[j]); }
+  wsync<1>();
+}
+__device__ __forceinline__ void lds_store_board(BoardRec& R, const Geo<1>& g, const uint32_t lab[], const uint32_t lastp[],
+                                                const Scalars& s, const Masks& m) {
+  GO_UNROLL
+  for (int k = 0; k < NWORDS; ++k)
+    if (g.p[k] < NPTS) { R.lab[g.p[k]] = (uint16_t)lab[k]; R.lastp[g.p[k]] = (uint16_t)lastp[k]; }
+  if (g.lane == 0) {
+    GO_UNROLL
+    for (int j = 0; j < NWORDS; ++j) { R.legal[j] = m.legal[j]; R.cand[j] = m.cand[j]; }
+  }
+  store_scalars(&R, s, g.tid);
 }
 
 // Rules wave: the snapshot of the position (lab, lastp, s) whose masks are `o`, reached by `action`.

@@ -432,7 +432,7 @@ class GoEnv:
         """Name of the kernel that the last generate() of this context launched."""
         pipe = C.c_int(0)
         self._chk(self.lib.goenv_generate_pace(self._h, None, None, C.byref(pipe)))
-        return "k_generate_pipe" if pipe.value else "k_generate"
+        return ("k_generate", "k_generate_pipe", "k_generate_pipe_multi")[pipe.value]
 
     def score(self, score_out=None, fast_out=None):
         self._check(score_out, torch.float32, (self.n,), "score_out")

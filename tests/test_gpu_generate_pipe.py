@@ -51,11 +51,14 @@ def same(x, y):
 
 @pytest.mark.parametrize("n,T,what,aug", [(64, 1, "fla", False), (37, 2, "fla", True), (100, 3, "fl", True),
                                           (96, 5, "la", False), (50, 9, "a", False), (130, 11, "f", True),
-                                          (300, 23, "fla", True)])
+                                          (300, 23, "fla", True),
+                                          # more boards than resident workgroups: several boards per workgroup, waiting
+                                          # in LDS (k_generate_pipe_multi), ragged last turn
+                                          (2500, 5, "fla", True), (4100, 3, "fl", False), (8200, 2, "fla", True)])
 def test_pipelined_equals_two_wave_kernel(goenv, monkeypatch, n, T, what, aug):
     out = []
     for pipe in (False, True):
-        env = make(goenv, monkeypatch, pipe, n, seed=5)
+        env = make(goenv, monkeypatch, pipe, n, seed=5, max_ply=80 if n < 2000 else 12)
         augs = ((torch.arange(n, dtype=torch.int32, device=env.device) * 3) % 8).contiguous() if aug else None
         got = []
         for _ in range(6):                              # launches follow one another: games end and restart inside
@@ -65,8 +68,11 @@ def test_pipelined_equals_two_wave_kernel(goenv, monkeypatch, n, T, what, aug):
             got += list(r)
         got += [v for _, v in sorted(env.get_state().items())]
         got.append(torch.tensor(env.stats()))
+        assert env.generate_kernel() == ("k_generate" if not pipe else ("k_generate_pipe" if n <= 2048 else "k_generate_pipe_multi"))
         out.append(got)
         env.close()
+        del r, got
+        torch.cuda.empty_cache()
     for i, (x, y) in enumerate(zip(*out)):
         assert same(x, y), (i, n, T, what)
     assert int(out[0][-1][goenv.ST_GAMES]) > 0 or T * 6 < 80
