@@ -329,7 +329,7 @@ def extra_measurements(goenv, seed):
     fr = torch.empty(T, B, 25, 19, 19, device=env.device)
     lr = torch.empty(T, B, 361, dtype=torch.uint8, device=env.device)
     ar = torch.empty(T, B, dtype=torch.int32, device=env.device)
-    for _ in range(6):
+    for _ in range(16):                       # the generator's rate limiter walks through its candidate paces first
         env.generate(T, fr, lr, ar)
     torch.cuda.synchronize()
     env.timer_begin()
@@ -338,7 +338,8 @@ def extra_measurements(goenv, seed):
     env.timer_end()
     ms = env.timer_ms() / (10 * T)
     res["generate_8192"] = {"ply_ms": ms, "moves_per_s": B / (ms * 1e-3), "plies_per_launch": T,
-                            "GBps": B * ALG_BYTES_PER_BOARD_PLY / (ms * 1e-3) / 1e9}
+                            "GBps": B * ALG_BYTES_PER_BOARD_PLY / (ms * 1e-3) / 1e9, "kernel": env.generate_kernel(),
+                            "store_pace_ns_per_board_ply": env.generate_pace()[0]}
     env.close()
     del fr, lr, ar
     torch.cuda.empty_cache()

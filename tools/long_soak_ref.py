@@ -5,7 +5,8 @@ the GPU box): every board of every launch replayed through the unmodified board.
 for millions of board-plies, through the three paths that write planes:
   k_ply<.,1>  launch per ply, on-device policy, games restarted in place     (B boards x PLIES)
   k_ply<.,2>  the fused selfplay step (move sampled from a reply pi)         (B boards x PLIES / 2)
-  k_generate  the bench line's kernel, rings of T plies                      (1,024 boards x 64 plies x LAUNCHES)
+  k_generate_pipe        the bench line's kernel, rings of T plies           (1,024 boards x 64 plies x LAUNCHES)
+  k_generate_pipe_multi  several boards per workgroup, D4 codes 0..7         (4,096 boards x 16 plies x LAUNCHES / 2)
 Usage: tools/long_soak_ref.py [boards] [plies] [generator launches]"""
 import os
 import sys
@@ -76,28 +77,30 @@ for t in range(PLIES // 2):
 print("k_ply<.,2>: %d boards x %d steps = %d board-plies, %d games finished: 0 mismatches" % (B, PLIES // 2, B * (PLIES // 2), restarts), flush=True)
 env.close()
 
-# --- the generator at the bench shape ---------------------------------------------------------------------
-GB, T = 1024, 64
-env = goenv.GoEnv(GB, seed=seed + 2, max_ply=cap)
-ref = RefBatch(GB)
-fr = torch.empty(T, GB, 25, 19, 19, device=env.device)
-lr = torch.empty(T, GB, 361, dtype=torch.uint8, device=env.device)
-ar = torch.empty(T, GB, dtype=torch.int32, device=env.device)
-games = np.zeros(GB, np.int32)
-zero = np.zeros(GB, np.int32)
-for L in range(LAUNCHES):
-    fr.fill_(-3.0)
-    env.generate(T, fr, lr, ar)
-    mv = ar.cpu().numpy()
-    for t in range(T):
-        for b in np.flatnonzero(ref.ended(cap)):
-            ref.board(int(b)).clear()
-            games[b] += 1
-        assert np.array_equal(mv[t], ref.policy(seed + 2, games)), "launch %d slot %d: moves" % (L, t)
-        ref.check(mv[t], None, None, lr[t].cpu().numpy(), fr[t].cpu().numpy(), zero, "launch %d slot %d" % (L, t))
-    total += GB * T
-ref.check(None, None, host_state(env), None, None, None, "records after the last launch")
-print("k_generate: %d boards x %d plies x %d launches = %d board-plies, %d games finished: 0 mismatches" % (
-    GB, T, LAUNCHES, GB * T * LAUNCHES, int(games.sum())), flush=True)
-env.close()
+# --- the generator: at the bench shape, and with several boards per workgroup under D4 codes ---------------
+for GB, T, launches, gcap, with_aug in ((1024, 64, LAUNCHES, cap, False), (4096, 16, max(1, LAUNCHES // 2), 200, True)):
+    env = goenv.GoEnv(GB, seed=seed + 2, max_ply=gcap)
+    ref = RefBatch(GB)
+    fr = torch.empty(T, GB, 25, 19, 19, device=env.device)
+    lr = torch.empty(T, GB, 361, dtype=torch.uint8, device=env.device)
+    ar = torch.empty(T, GB, dtype=torch.int32, device=env.device)
+    games = np.zeros(GB, np.int32)
+    gaug = (np.arange(GB) % 8).astype(np.int32) if with_aug else np.zeros(GB, np.int32)
+    gaugs = torch.from_numpy(gaug).to(env.device) if with_aug else None
+    for L in range(launches):
+        fr.fill_(-3.0)
+        env.generate(T, fr, lr, ar, aug_codes=gaugs)
+        mv = ar.cpu().numpy()
+        for t in range(T):
+            for b in np.flatnonzero(ref.ended(gcap)):
+                ref.board(int(b)).clear()
+                games[b] += 1
+            assert np.array_equal(mv[t], ref.policy(seed + 2, games)), "launch %d slot %d: moves" % (L, t)
+            ref.check(mv[t], None, None, lr[t].cpu().numpy(), fr[t].cpu().numpy(), gaug, "launch %d slot %d" % (L, t))
+        total += GB * T
+    ref.check(None, None, host_state(env), None, None, None, "records after the last launch")
+    print("%s: %d boards x %d plies x %d launches = %d board-plies, %d games finished: 0 mismatches" % (
+        env.generate_kernel(), GB, T, launches, GB * T * launches, int(games.sum())), flush=True)
+    env.close()
+    del fr, lr, ar
 print("TOTAL %d board-plies against the reference itself, every float: 0 mismatches, %.0f s" % (total, time.time() - t0), flush=True)
