@@ -1293,6 +1293,7 @@ struct goenv_ctx {
   int gen_pace_ns;                     // its rate limiter, ns between two samples of a board: -1 = tuned (default),
                                        // else pinned, 0 = none (GOENV_GEN_PACE_NS)
   int gen_resident;                    // boards of k_generate_pipe that the device holds at once (0: not asked yet)
+  int wall_khz;                        // rate of the wall clock that the rate limiter reads (s_memrealtime: 100 MHz on gfx950)
   int gen_last_pipe;                   // the last goenv_generate went through k_generate_pipe (1) / _multi (2)
   int gen_multi_m, gen_multi_grid;     // k_generate_pipe_multi: boards per workgroup (0: not asked yet, -1: none fits), grid
   GenTune tune;
@@ -2106,6 +2107,9 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
   // 512 .. 2,048 boards: -18 %).  Beyond, workgroups run in rounds and a clock-driven schedule has no meaning: two or three
   // waves per board that share rules and stores (k_generate; tools/time_generate.py).
   if (!c->gen_resident) {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
+    c->wall_khz = khz;
     int per_cu = 0, cus = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_generate_pipe, 128, 0));
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
@@ -2132,10 +2136,10 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
     HIPCHK(hipGetLastError());
     return 0;
   }
-  int pace_ticks = 0;   // 10-ns ticks of the wall clock
+  int pace_ticks = 0;   // ticks of the wall clock (10 ns)
   GenTune::Pend* timed = nullptr;
   if (c->gen_pace_ns >= 0) {
-    pace_ticks = (resident || multi) ? c->gen_pace_ns / 10 : 0;
+    pace_ticks = (resident || multi) ? (int)((double)c->gen_pace_ns * c->wall_khz * 1e-6) : 0;
   } else if ((resident || multi) && P.feat) {
     GenTune& t = c->tune;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -2160,7 +2164,7 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
         if (t.samples[i] && (best < 0 || t.est[i] < t.est[best])) cand = best = i;
     }
     // with several boards per workgroup the cliff sits 8 % further up (measured: 6.8 ns per board-ply at 4,096 boards, 7.2 at 8,192)
-    pace_ticks = (int)(GenTune::cand[cand] * (multi ? 1.08f : 1.f) * (float)c->n / 10.f);
+    pace_ticks = (int)((double)GenTune::cand[cand] * (multi ? 1.08 : 1.0) * c->n * c->wall_khz * 1e-6);
   }
   if (timed) HIPCHK(hipEventRecord(timed->e0, S(stream)));
   if (multi)   // pace_ticks: the time of one ply of ALL boards; a workgroup divides it by its boards
