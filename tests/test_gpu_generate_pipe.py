@@ -158,3 +158,27 @@ def test_rate_limiter_tunes_itself_and_changes_no_byte(goenv, monkeypatch):
     assert ref.generate_pace()[0] == 0.0
     tuned.close()
     ref.close()
+
+
+def test_first_call_inside_a_capture(goenv, monkeypatch):
+    """A context whose very first goenv_generate is recorded into a graph: the tuner records no event there and uses its safe
+    pace; the replays continue the games exactly as plain calls on a twin context do."""
+    n, T, seed = 1024, 6, 21
+    monkeypatch.delenv("GOENV_GEN_PIPE", raising=False)
+    monkeypatch.delenv("GOENV_GEN_PACE_NS", raising=False)
+    plain = goenv.GoEnv(n, seed=seed, max_ply=722)
+    cold = goenv.GoEnv(n, seed=seed, max_ply=722)
+    rp, rc = rings(plain, T, "fla", None), rings(cold, T, "fla", None)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cold.generate(T, *rc)
+    for _ in range(4):
+        plain.generate(T, *rp)
+        g.replay()
+        torch.cuda.synchronize()
+        for x, y in zip(rp, rc):
+            assert same(x, y)
+    assert cold.generate_kernel() == "k_generate_pipe" and cold.generate_pace()[0] == 0.0   # nothing was timed
+    plain.close()
+    cold.close()
