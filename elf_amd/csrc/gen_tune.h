@@ -1,0 +1,51 @@
+// gen_tune.h -- the self-tuning pace of the pipelined generator's rate limiter (host logic only: no HIP in here, so that
+// tests/test_gen_tune.py can drive it on the CPU against a made-up cost curve).
+//
+// The offered store rate that the memory side takes best differs from card to card by a few per cent (cliff measured at
+// 6.0 .. 6.5 ns per board-ply), and offering more than that costs 10 % (profiles/r03_pipe_generator.md).  goenv_generate
+// times its own launches (events recorded around the kernel, read back later without waiting) and moves between a few
+// candidate paces: every candidate twice in turn, then the best one by a running estimate, with a neighbour tried every
+// sixteenth launch because a card's state drifts.  The pace changes WHEN samples are written, never what is written.
+#pragma once
+
+struct GenTuneCore {
+  static constexpr int NC = 6;
+  // ns per board-ply offered: 36,465 B / 6.75 ns = 5.40 TB/s is the safe side of every cliff seen
+  static constexpr float cand[NC] = {6.10f, 6.25f, 6.40f, 6.55f, 6.75f, 7.10f};
+  static constexpr int SAFE = 4;
+  float est[NC];          // us per ply, running estimate (valid where samples > 0)
+  int samples[NC], launched[NC];
+  int launches;
+
+  // best candidate by the estimates so far; -1: nothing has come back yet
+  int best() const {
+    int b = -1;
+    for (int i = 0; i < NC; ++i)
+      if (samples[i] && (b < 0 || est[i] < est[b])) b = i;
+    return b;
+  }
+  // the candidate of the next timed launch
+  int pick() const {
+    for (int round = 1; round <= 2; ++round)          // every candidate twice, in turn
+      for (int i = 0; i < NC; ++i)
+        if (launched[i] < round) return i;
+    const int b = best();
+    if (b < 0) return SAFE;
+    if (launches % 16 == 15) {                        // now and then a neighbour
+      const int nb = b + (((launches >> 4) & 1) ? 1 : -1);
+      if (nb >= 0 && nb < NC) return nb;
+    }
+    return b;
+  }
+  // a launch with candidate c has been enqueued (timed: its duration will be reported by result())
+  void enqueued(int c, bool timed) {
+    if (timed) launched[c] += 1;
+    launches += 1;
+  }
+  // a timed launch with candidate c took us_per_ply
+  void result(int c, float us_per_ply) {
+    est[c] = samples[c] ? 0.5f * (est[c] + us_per_ply) : us_per_ply;
+    samples[c] += 1;
+  }
+};
+constexpr float GenTuneCore::cand[GenTuneCore::NC];

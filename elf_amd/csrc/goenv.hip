@@ -17,6 +17,7 @@
 
 #include "../../include/goenv.h"
 #include "goenv_device.h"
+#include "gen_tune.h"
 #include "goenv_tactics.h"
 
 using namespace goenv;
@@ -1242,23 +1243,12 @@ static size_t g_lds_pad = getenv("GOENV_LDS_PAD") ? (size_t)atoi(getenv("GOENV_L
 // host side
 // ----------------------------------------------------------------------------------------------
 
-// The rate limiter of k_generate_pipe tunes itself: the offered store rate that the memory side takes best differs from
-// card to card by a few per cent (cliff measured at 6.0 .. 6.5 ns per board-ply), and offering more than that costs 10 %
-// (profiles/r03_pipe_generator.md).  goenv_generate times its own launches with events (recorded around the kernel, read
-// back later without waiting) and moves between a few candidate paces: every candidate twice in turn, then the best one,
-// with a neighbour tried now and then.  The pace changes WHEN samples are written, never what is written.
-struct GenTune {
-  static constexpr int NC = 6, NPEND = 8;
-  // ns per board-ply offered: 36,465 B / 6.75 ns = 5.40 TB/s is the safe side of every cliff seen
-  static constexpr float cand[NC] = {6.10f, 6.25f, 6.40f, 6.55f, 6.75f, 7.10f};
-  static constexpr int SAFE = 4;
-  float est[NC];          // us per ply, running estimate (0: none yet)
-  int samples[NC], launched[NC];
-  int launches;
+// the tuner's logic (gen_tune.h) + the events of launches whose time has not been read back yet
+struct GenTune : GenTuneCore {
+  static constexpr int NPEND = 8;
   struct Pend { hipEvent_t e0, e1; int cand, plies, busy; } pend[NPEND];
   int events_ready;
 };
-constexpr float GenTune::cand[GenTune::NC];
 
 struct goenv_ctx {
   int device;
@@ -2068,30 +2058,10 @@ static void gen_tune_collect(GenTune& t) {
     GenTune::Pend& p = t.pend[i];
     if (!p.busy || hipEventQuery(p.e1) != hipSuccess) continue;
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess && ms > 0.f) {
-      const float us = ms * 1e3f / (float)p.plies;
-      t.est[p.cand] = t.samples[p.cand] ? 0.5f * (t.est[p.cand] + us) : us;
-      t.samples[p.cand] += 1;
-    }
+    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess && ms > 0.f) t.result(p.cand, ms * 1e3f / (float)p.plies);
     p.busy = 0;
   }
   (void)hipGetLastError();   // hipEventQuery reports "not ready" as an error
-}
-
-// the candidate of the next launch
-static int gen_tune_pick(GenTune& t) {
-  for (int round = 1; round <= 2; ++round)          // every candidate twice, in turn
-    for (int i = 0; i < GenTune::NC; ++i)
-      if (t.launched[i] < round) return i;
-  int best = -1;
-  for (int i = 0; i < GenTune::NC; ++i)
-    if (t.samples[i] && (best < 0 || t.est[i] < t.est[best])) best = i;
-  if (best < 0) return GenTune::SAFE;               // nothing has come back yet
-  if (t.launches % 16 == 15) {                      // now and then a neighbour: the card's state drifts
-    const int nb = best + (((t.launches >> 4) & 1) ? 1 : -1);
-    if (nb >= 0 && nb < GenTune::NC) return nb;
-  }
-  return best;
 }
 
 int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* feat_ring, uint8_t* legal_ring,
@@ -2154,14 +2124,13 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
         t.events_ready = 1;
       }
       gen_tune_collect(t);
-      cand = gen_tune_pick(t);
+      cand = t.pick();
       for (int i = 0; i < GenTune::NPEND && !timed; ++i)
         if (!t.pend[i].busy) timed = &t.pend[i];
-      if (timed) { timed->cand = cand; timed->plies = n_plies; t.launched[cand] += 1; }
-      t.launches += 1;
-    } else {
-      for (int i = 0, best = -1; i < GenTune::NC; ++i)
-        if (t.samples[i] && (best < 0 || t.est[i] < t.est[best])) cand = best = i;
+      if (timed) { timed->cand = cand; timed->plies = n_plies; }
+      t.enqueued(cand, timed != nullptr);
+    } else if (t.best() >= 0) {
+      cand = t.best();
     }
     // with several boards per workgroup the cliff sits 8 % further up (measured: 6.8 ns per board-ply at 4,096 boards, 7.2 at 8,192)
     pace_ticks = (int)((double)GenTune::cand[cand] * (multi ? 1.08 : 1.0) * c->n * c->wall_khz * 1e-6);
@@ -2188,11 +2157,9 @@ int goenv_generate_pace(goenv_ctx* c, float* pace_ns_per_board_out, float* est_o
   if (pipelined_out) *pipelined_out = c->gen_last_pipe;
   GenTune& t = c->tune;
   if (t.events_ready) gen_tune_collect(t);
-  int best = -1;
-  for (int i = 0; i < GenTune::NC; ++i) {
+  const int best = t.best();
+  for (int i = 0; i < GenTune::NC; ++i)
     if (est_out) est_out[i] = t.samples[i] ? t.est[i] : 0.f;
-    if (t.samples[i] && (best < 0 || t.est[i] < t.est[best])) best = i;
-  }
   if (pace_ns_per_board_out) *pace_ns_per_board_out = best < 0 ? 0.f : GenTune::cand[best] * (c->gen_last_pipe == 2 ? 1.08f : 1.f);
   return 0;
 }
