@@ -1372,7 +1372,7 @@ struct DeviceScope {
 
 extern "C" {
 
-int goenv_version(void) { return 3; }
+int goenv_version(void) { return 4; }
 
 const char* goenv_last_error(void) { return g_err.c_str(); }
 

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(goenv.LIB_PATH)
     for name in header_symbols():
         assert hasattr(lib, name), name
-    assert goenv.load_library().goenv_version() == 3
+    assert goenv.load_library().goenv_version() == 4
 
 
 def test_d4_host_helpers_match_reference_tables():
