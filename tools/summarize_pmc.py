@@ -6,7 +6,7 @@ HBM bytes are corrected as MI355X_MICROARCH.md (HBM / rocprofv3 section) prescri
 WRITE_SIZE are reported in KB; FETCH_SIZE is doubled on gfx950.
 Usage: tools/summarize_pmc.py [--last=N] gpurun_out/<tag> <round> [kernel boards plies per_ply_bytes per_launch_bytes]
        (--last=N: only the last N launches of the kernel, for commands whose set-up uses the same kernel)
-       e.g. ... gpurun_out/r02a r02                                   (the bench line: k_generate<2>, 1,024 x 64)
+       e.g. ... gpurun_out/r3p r03                                    (the bench line: k_generate_pipe, 1,024 x 128)
             ... gpurun_out/r02g8 r02_generate_8192 "k_generate<3>" 8192 20
             ... gpurun_out/r02p8 r02_ply_8192 "k_ply<3, 1>" 8192 1 36461 3264   (launch per ply)"""
 import csv
@@ -17,9 +17,9 @@ import subprocess
 import sys
 from collections import defaultdict
 
-KERNEL = "k_generate<2>"
+KERNEL = "k_generate_pipe"
 BOARDS = 1024
-PLIES = 64                                   # plies per launch of the profiled command (--steps 512)
+PLIES = 128                                  # plies per launch of the profiled command (bench.py --ring)
 ALGO_PER_BOARD_PLY = 36100 + 361 + 4         # planes + mask + move, per board per ply
 ALGO_PER_BOARD_LAUNCH = 1632 + 1632          # record read + record write, once per launch
 
