@@ -160,10 +160,14 @@ def test_fused_selfplay_step_against_the_reference(goenv):
         env.close()
 
 
-def test_generator_rings_against_the_reference(goenv):
-    """The bench line's kernel (goenv_generate, 1,024 boards x 64 plies per launch): every ring slot -- move,
-    mask, all planes -- against reference boards that are restarted where the device restarts its games."""
-    boards, plies, launches, seed, cap = 1024, 64, 3, 31, 90
+@pytest.mark.parametrize("boards,plies,launches,cap,kernel,with_aug", [
+    (1024, 64, 3, 90, "k_generate_pipe", False),          # the bench line's shape
+    (2600, 12, 4, 40, "k_generate_pipe_multi", True),     # several boards per workgroup, D4 codes, ragged last turn
+])
+def test_generator_rings_against_the_reference(goenv, boards, plies, launches, cap, kernel, with_aug):
+    """goenv_generate through both pipelined kernels: every ring slot -- move, mask, all planes -- against reference boards
+    that are restarted where the device restarts its games."""
+    seed = 31
     env = goenv.GoEnv(boards, seed=seed, max_ply=cap)
     dev = env.device
     ref = RefBatch(boards)
@@ -171,12 +175,14 @@ def test_generator_rings_against_the_reference(goenv):
     legal = torch.empty(plies, boards, 361, dtype=torch.uint8, device=dev)
     moves = torch.empty(plies, boards, dtype=torch.int32, device=dev)
     games = np.zeros(boards, np.int32)
-    zero = np.zeros(boards, np.int32)
+    zero = ((np.arange(boards) * 3) % 8).astype(np.int32) if with_aug else np.zeros(boards, np.int32)
+    augs = torch.from_numpy(zero).to(dev) if with_aug else None
     restarts = 0
     for _ in range(launches):
         feat.fill_(-3.0)
         legal.fill_(9)
-        env.generate(plies, feat, legal, moves)
+        env.generate(plies, feat, legal, moves, aug_codes=augs)
+        assert env.generate_kernel() == kernel
         mv = moves.cpu().numpy()
         for t in range(plies):
             for b in np.flatnonzero(ref.ended(cap)):      # the device restarts these before this ply
