@@ -846,7 +846,7 @@ __global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_
   __shared__ BoardLds<1> L;
   __shared__ PipeLds X;
   extern __shared__ __align__(16) unsigned char saved_raw[];
-  BoardRec* saved = reinterpret_cast<BoardRec*>(saved_raw);
+  SavedBoard* saved = reinterpret_cast<SavedBoard*>(saved_raw);
   const int G = (int)gridDim.x, w = (int)blockIdx.x, n = P.n;
   const int mine = w < n ? (n - 1 - w) / G + 1 : 0;          // boards of this workgroup
   // its i-th board: turn i of the grid covers the rows [i G, (i + 1) G) of a slot -- one window of the output at a time, each XCD
@@ -863,12 +863,7 @@ __global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_
   const int lane = (int)(threadIdx.x & 63);
   if (threadIdx.x == 0) { X.produced = 0; X.consumed = 0; }
   for (int i = threadIdx.x; i < PIPE_LUT_N; i += 128) X.lut[i] = P.lut[i];
-  constexpr int REC_VEC = (int)(sizeof(BoardRec) / 16);
-  for (int i = 0; i < mine; ++i) {
-    const uint4* src = reinterpret_cast<const uint4*>(P.state + board_at(i));
-    uint4* dst = reinterpret_cast<uint4*>(saved + i);
-    for (int v = threadIdx.x; v < REC_VEC; v += 128) dst[v] = src[v];
-  }
+  for (int i = 0; i < mine; ++i) saved_from_record(saved[i], P.state + board_at(i), (int)threadIdx.x, 128);
   __syncthreads();   // the only barrier of the kernel
   const int items = mine * n_plies;
   if (wave == 0) {
@@ -901,11 +896,7 @@ __global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_
       }
     }
     wsync<1>();
-    for (int i = 0; i < mine; ++i) {
-      uint4* dst = reinterpret_cast<uint4*>(P.state + board_at(i));
-      const uint4* src = reinterpret_cast<const uint4*>(saved + i);
-      for (int v = lane; v < REC_VEC; v += 64) dst[v] = src[v];
-    }
+    for (int i = 0; i < mine; ++i) record_from_saved(P.state + board_at(i), saved[i], lane, 64);
   } else {
     const int period = mine > 0 ? ply_period_ticks / mine : 0;
     int src[8], cur_aug = -1;
@@ -2072,10 +2063,11 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
   if (n_plies == 0) return 0;
   PlyParams P = make_params(c, GOENV_F_RANDOM_POLICY | GOENV_F_AUTO_RESTART, nullptr, aug_codes, feat_ring, legal_ring,
                             nullptr, nullptr);
-  // Up to the number of boards that the device holds at once (2,304 on an MI355X): a rules wave and a feature wave per
-  // board, pipelined through LDS, the feature waves rate-limited (k_generate_pipe; 1,024 boards: 7.7 -> 6.9 us per ply,
-  // 512 .. 2,048 boards: -18 %).  Beyond, workgroups run in rounds and a clock-driven schedule has no meaning: two or three
-  // waves per board that share rules and stores (k_generate; tools/time_generate.py).
+  // A rules wave and a feature wave per workgroup, pipelined through LDS, the feature waves rate-limited: one board per
+  // workgroup while that keeps the device's storing waves few (k_generate_pipe; 1,024 boards: 7.7 -> 6.9 us per ply, 256 ..
+  // 1,536 boards: -18 %), several boards per workgroup beyond (k_generate_pipe_multi, up to about 14,000 boards).  Where
+  // neither fits, workgroups would run in rounds and a clock-driven schedule has no meaning: two or three waves per board
+  // that share rules and stores (k_generate; tools/time_generate.py).
   if (!c->gen_resident) {
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
@@ -2085,19 +2077,34 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
     c->gen_resident = per_cu * cus > 0 ? per_cu * cus : -1;
   }
-  const bool resident = c->n <= c->gen_resident;
-  // more boards than that: several boards per resident workgroup, waiting in LDS (k_generate_pipe_multi), up to 16 each
-  if (!resident && !c->gen_multi_m && c->gen_resident > 0) {
+  // How many boards a workgroup holds (gen_multi_m: 1 = k_generate_pipe; 2 .. 16 = k_generate_pipe_multi, the others waiting
+  // in LDS; -1 = neither fits).  Measured (profiles/r03_pipe_generator.md, section 11): the memory side takes the plane stream
+  // best from about 1,024 storing waves -- four workgroups on every CU, one wave pair per SIMD -- at 6.5 ns per board-ply;
+  // from five to eight workgroups per CU it takes 6.9; an uneven number per CU costs its imbalance; and a rules wave needs
+  // 6.9 us for a board's turn.  The cheapest of the shapes that fit:
+  if (!c->gen_multi_m) {
+    int cus = 0;
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    double best_cost = 0;
     c->gen_multi_m = -1;
-    for (int m = 2; m <= 16 && c->gen_multi_m < 0; ++m) {
-      int per_cu = 0, cus = 0;
-      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_generate_pipe_multi, 128, (size_t)m * sizeof(BoardRec)));
-      HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-      const int grid = (((c->n + m - 1) / m + 7) / 8) * 8;
-      if (grid <= per_cu * cus) { c->gen_multi_m = m; c->gen_multi_grid = grid; }
+    int forced = 0;
+    if (const char* e = getenv("GOENV_GEN_MULTI_M")) forced = atoi(e);   // tuning only
+    for (int m = 1; m <= 16; ++m) {
+      if (forced && m != forced) continue;
+      const int grid = m == 1 ? c->n : (((c->n + m - 1) / m + 7) / 8) * 8;
+      int per_cu = 0;
+      if (m == 1) per_cu = c->gen_resident > 0 ? c->gen_resident / (cus > 0 ? cus : 1) : 0;
+      else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_generate_pipe_multi, 128, (size_t)m * sizeof(SavedBoard)));
+      if (grid > per_cu * cus || (m > 1 && !forced && grid > 4 * cus)) continue;
+      const int k = (grid + cus - 1) / cus;                               // workgroups on the fullest CU
+      const double imbalance = (double)k * cus / grid;
+      double cost = c->n * (k <= 4 ? 6.5 : 6.9) * imbalance;              // ns per ply, store side
+      if (m > 1 && cost < m * 6900.0) cost = m * 6900.0;                  // rules side
+      if (c->gen_multi_m < 0 || cost < best_cost) { c->gen_multi_m = m; c->gen_multi_grid = grid; best_cost = cost; }
     }
   }
-  const bool multi = !resident && c->gen_multi_m > 0 && !c->nw && c->gen_pipe != 0;
+  const bool resident = c->gen_multi_m == 1;
+  const bool multi = c->gen_multi_m > 1 && !c->nw && c->gen_pipe != 0;
   const bool pipe = c->nw ? false : (c->gen_pipe < 0 ? (resident || multi) : c->gen_pipe != 0);
   c->gen_last_pipe = pipe ? (multi ? 2 : 1) : 0;
   if (!pipe) {
@@ -2132,12 +2139,11 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
     } else if (t.best() >= 0) {
       cand = t.best();
     }
-    // with several boards per workgroup the cliff sits 8 % further up (measured: 6.8 ns per board-ply at 4,096 boards, 7.2 at 8,192)
-    pace_ticks = (int)((double)GenTune::cand[cand] * (multi ? 1.08 : 1.0) * c->n * c->wall_khz * 1e-6);
+    pace_ticks = (int)((double)GenTune::cand[cand] * c->n * c->wall_khz * 1e-6);
   }
   if (timed) HIPCHK(hipEventRecord(timed->e0, S(stream)));
   if (multi)   // pace_ticks: the time of one ply of ALL boards; a workgroup divides it by its boards
-    hipLaunchKernelGGL(k_generate_pipe_multi, dim3(c->gen_multi_grid), dim3(128), (size_t)c->gen_multi_m * sizeof(BoardRec),
+    hipLaunchKernelGGL(k_generate_pipe_multi, dim3(c->gen_multi_grid), dim3(128), (size_t)c->gen_multi_m * sizeof(SavedBoard),
                        S(stream), P, n_plies, actions_ring, pace_ticks);
   else
     hipLaunchKernelGGL(k_generate_pipe, dim3(c->n), dim3(128), 0, S(stream), P, n_plies, actions_ring, pace_ticks);
@@ -2160,7 +2166,7 @@ int goenv_generate_pace(goenv_ctx* c, float* pace_ns_per_board_out, float* est_o
   const int best = t.best();
   for (int i = 0; i < GenTune::NC; ++i)
     if (est_out) est_out[i] = t.samples[i] ? t.est[i] : 0.f;
-  if (pace_ns_per_board_out) *pace_ns_per_board_out = best < 0 ? 0.f : GenTune::cand[best] * (c->gen_last_pipe == 2 ? 1.08f : 1.f);
+  if (pace_ns_per_board_out) *pace_ns_per_board_out = best < 0 ? 0.f : GenTune::cand[best];
   return 0;
 }
 

@@ -32,6 +32,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace goenv {
@@ -1060,38 +1061,71 @@ __device__ __forceinline__ void snapshot_load(const PipeSnap& S, int lane, const
   r.wb[NWORDS] = 0; r.ww[NWORDS] = 0;
 }
 
-// A board that waits for its next turn in LDS (k_generate_pipe_multi: several boards per workgroup), in the record's own
-// layout.  One wave; the label image's rim is the caller's.
-__device__ __forceinline__ void lds_load_board(const BoardRec& R, BoardLds<1>& L, const Geo<1>& g, uint32_t lab[],
+// A board that waits for its next turn in LDS (k_generate_pipe_multi: several boards per workgroup): the record with its two
+// per-point tables packed into one dword per point (label | last_placed << 16), so that a turn starts with six LDS reads per
+// lane, and the 40 uniform dwords behind them (scalars, legal and candidate words) read ONCE, by lane, and handed out with
+// v_readlane.  Same size as the record: 1,632 B.
+struct __attribute__((aligned(16))) SavedBoard {
+  uint32_t raw[TAB_N];
+  uint32_t uni[40];       // legal[6] as 12 dwords | cand[6] as 12 dwords | sc[16]: where the record has them
+};
+static_assert(sizeof(SavedBoard) == sizeof(BoardRec) && offsetof(BoardRec, legal) == offsetof(SavedBoard, uni) &&
+                  offsetof(BoardRec, sc) == offsetof(SavedBoard, uni) + 24 * 4,
+              "a saved board is a record with its two tables packed");
+
+// One wave; the label image's rim is the caller's.
+__device__ __forceinline__ void lds_load_board(const SavedBoard& R, BoardLds<1>& L, const Geo<1>& g, uint32_t lab[],
                                                uint32_t lastp[], Scalars& s, Masks& m) {
   GO_UNROLL
   for (int k = 0; k < NWORDS; ++k) {
     const bool v = g.p[k] < NPTS;
-    lab[k] = v ? R.lab[g.p[k]] : 0u;
-    lastp[k] = v ? R.lastp[g.p[k]] : 0u;
+    const uint32_t r = v ? R.raw[g.p[k]] : 0u;
+    lab[k] = r & 0xffffu;
+    lastp[k] = r >> 16;
     if (v) L.lab[g.c[k]] = (uint16_t)lab[k];
   }
-  int sc[16];
+  const int mine = (int)R.uni[g.lane < 40 ? g.lane : 0];
+  int u[40];
   GO_UNROLL
-  for (int i = 0; i < 16; ++i) sc[i] = __builtin_amdgcn_readfirstlane(R.sc[i]);
+  for (int i = 0; i < 40; ++i) u[i] = __builtin_amdgcn_readlane(mine, i);
+  const int* sc = u + 24;
   s.ply = sc[SC_PLY]; s.next = sc[SC_NEXT]; s.bcap = sc[SC_BCAP]; s.wcap = sc[SC_WCAP];
   s.l1 = sc[SC_L1]; s.l2 = sc[SC_L2]; s.l3 = sc[SC_L3]; s.l4 = sc[SC_L4];
   s.koage = sc[SC_KOAGE]; s.ko = sc[SC_KO]; s.kocolor = sc[SC_KOCOLOR];
   s.done = sc[SC_DONE]; s.game = sc[SC_GAME]; s.counted = sc[SC_COUNTED]; s.seq = sc[SC_SEQ]; s.seqtot = sc[SC_SEQTOT];
   GO_UNROLL
-  for (int j = 0; j < NWORDS; ++j) { m.legal[j] = uni64(R.legal[j]); m.cand[j] = uni64(R.cand[j]); }
+  for (int j = 0; j < NWORDS; ++j) {
+    m.legal[j] = ((unsigned long long)(uint32_t)u[1 + 2 * j] << 32) | (uint32_t)u[2 * j];
+    m.cand[j] = ((unsigned long long)(uint32_t)u[13 + 2 * j] << 32) | (uint32_t)u[12 + 2 * j];
+  }
   wsync<1>();
 }
-__device__ __forceinline__ void lds_store_board(BoardRec& R, const Geo<1>& g, const uint32_t lab[], const uint32_t lastp[],
+__device__ __forceinline__ void lds_store_board(SavedBoard& R, const Geo<1>& g, const uint32_t lab[], const uint32_t lastp[],
                                                 const Scalars& s, const Masks& m) {
   GO_UNROLL
   for (int k = 0; k < NWORDS; ++k)
-    if (g.p[k] < NPTS) { R.lab[g.p[k]] = (uint16_t)lab[k]; R.lastp[g.p[k]] = (uint16_t)lastp[k]; }
+    if (g.p[k] < NPTS) R.raw[g.p[k]] = (lab[k] & 0xffffu) | (lastp[k] << 16);
   if (g.lane == 0) {
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(R.uni);
     GO_UNROLL
-    for (int j = 0; j < NWORDS; ++j) { R.legal[j] = m.legal[j]; R.cand[j] = m.cand[j]; }
+    for (int j = 0; j < NWORDS; ++j) { w[j] = m.legal[j]; w[NWORDS + j] = m.cand[j]; }
   }
-  store_scalars(&R, s, g.tid);
+  store_scalars(reinterpret_cast<BoardRec*>(&R), s, g.tid);   // sc[] sits where the record has it
+}
+// record <-> saved board, by `nthreads` threads of which this is thread `tid`
+__device__ __forceinline__ void saved_from_record(SavedBoard& S, const BoardRec* rec, int tid, int nthreads) {
+  for (int p = tid; p < TAB_N; p += nthreads) S.raw[p] = (uint32_t)rec->lab[p] | ((uint32_t)rec->lastp[p] << 16);
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(rec->legal);   // legal[6], cand[6], sc[16] are contiguous in the record
+  for (int i = tid; i < 40; i += nthreads) S.uni[i] = src[i];
+}
+__device__ __forceinline__ void record_from_saved(BoardRec* rec, const SavedBoard& S, int tid, int nthreads) {
+  for (int p = tid; p < TAB_N; p += nthreads) {
+    const uint32_t r = S.raw[p];
+    rec->lab[p] = (uint16_t)(r & 0xffffu);
+    rec->lastp[p] = (uint16_t)(r >> 16);
+  }
+  uint32_t* dst = reinterpret_cast<uint32_t*>(rec->legal);
+  for (int i = tid; i < 40; i += nthreads) dst[i] = S.uni[i];
 }
 
 // Rules wave: the snapshot of the position (lab, lastp, s) whose masks are `o`, reached by `action`.

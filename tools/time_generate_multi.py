@@ -64,7 +64,7 @@ if mode == "--one":
     print("%5d boards x %3d plies %-22s us per ply by group of 8 launches: %s | pace %.2f, estimates %s" % (
         B, T, env.generate_kernel(), " ".join("%.2f" % x for x in out), pace, " ".join("%.2f" % e for e in est)), flush=True)
     sys.exit(0)
-for B, T in ((3072, 32), (4096, 32), (8192, 16), (16384, 8)):
+for B, T in ((1800, 32), (2048, 32), (2560, 32), (3072, 32), (4096, 32), (6144, 16), (8192, 16), (12288, 8), (16384, 8)):
     for pipe in ("0", None):
         env = dict(os.environ)
         env.pop("GOENV_GEN_PIPE", None)
