@@ -865,6 +865,12 @@ __global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_
   for (int i = threadIdx.x; i < PIPE_LUT_N; i += 128) X.lut[i] = P.lut[i];
   for (int i = 0; i < mine; ++i) saved_from_record(saved[i], P.state + board_at(i), (int)threadIdx.x, 128);
   __syncthreads();   // the only barrier of the kernel
+#ifdef GOENV_STAMPS
+  unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk_ = wall_clock64();
+#define PTICK(i) do { const unsigned long long n_ = wall_clock64(); acc_[i] += n_ - tk_; tk_ = n_; } while (0)
+#else
+#define PTICK(i) do { } while (0)
+#endif
   const int items = mine * n_plies;
   if (wave == 0) {
     Geo<1> g;
@@ -879,20 +885,26 @@ __global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_
         uint32_t lab[NWORDS], lastp[NWORDS];
         Masks m;
         Own<1> o;
+        PTICK(0);
         lds_load_board(saved[i], L, g, lab, lastp, s, m);
         own_from_masks(g, m, o);
+        PTICK(1);
         if (s.done) {
           if (!s.counted) account_game(P.stats, g.tid, s, tromp_taylor(L, g, lab), P.komi);
           restart_in_place(L, g, lab, lastp, s, m, o);
         }
         const int a = ply_body<1, true>(L, g, lab, lastp, s, m, o, P, b, 0ll);
         gather_masks(L, g, o, m);
+        PTICK(2);
         lds_store_board(saved[i], g, lab, lastp, s, m);
+        PTICK(3);
         if (j >= PIPE_DEPTH) pipe_wait(&X.consumed, j - PIPE_DEPTH + 1);
+        PTICK(4);
         PipeSnap& S = X.snap[j % PIPE_DEPTH];
         snapshot_write(S, g, lab, lastp, s, o, a);
         if (g.lane == 0) { S.aug = P.aug ? (P.aug[b] & 7) : 0; S.row = b; }
         pipe_post(&X.produced, j + 1, g.lane);
+        PTICK(5);
       }
     }
     wsync<1>();
@@ -903,7 +915,9 @@ __global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_
     unsigned long long next = wall_clock64();
     int t = 0, i = 0;
     for (int j = 0; j < items; ++j) {
+      PTICK(0);
       pipe_wait(&X.produced, j + 1);
+      PTICK(1);
       const PipeSnap& S = X.snap[j % PIPE_DEPTH];
       const int aug = __builtin_amdgcn_readfirstlane(S.aug), b = __builtin_amdgcn_readfirstlane(S.row);
       if (aug != cur_aug) {
@@ -916,6 +930,7 @@ __global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_
       SnapRegs r;
       snapshot_load(S, lane, src, r);
       pipe_post(&X.consumed, j + 1, lane);
+      PTICK(2);
       if (period) {   // the rate limiter of k_generate_pipe, one sample per period
         unsigned long long now = wall_clock64();
         for (int spin = 0; spin < 4096 && now < next; ++spin) {   // bounded: a wave always gets out
@@ -925,6 +940,7 @@ __global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_
         next = (now > next + 2ull * (unsigned long long)period) ? now + (unsigned long long)period
                                                                  : next + (unsigned long long)period;
       }
+      PTICK(3);
       const size_t row = (size_t)t * n + b;
       if (actions_ring && lane == 0) actions_ring[row] = r.action;
       uint8_t* lg = P.legal ? P.legal + row * NPTS : nullptr;
@@ -940,6 +956,12 @@ __global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_
       if (++i == mine) { i = 0; ++t; }
     }
   }
+#ifdef GOENV_STAMPS
+  PTICK(6);
+  if (P.stamps && (threadIdx.x & 63) == 0)
+    for (int i = 0; i < 8; ++i) P.stamps[(size_t)blockIdx.x * 32 + wave * 16 + i] = acc_[i];
+#endif
+#undef PTICK
 }
 
 // Replay of given move lists (SGF records packed on the host): row b applies
@@ -1658,7 +1680,11 @@ extern "C" int goenv_diag_generate(goenv_ctx* c, int n_plies, float* feat_ring, 
                             nullptr, nullptr);
   P.stamps = stamps;
   const int nw = c->nw ? c->nw : (c->n <= 4096 ? 2 : 3);
-  if (c->gen_pipe > 0) hipLaunchKernelGGL(k_generate_pipe, dim3(c->n), dim3(128), 0, S(stream), P, n_plies, (int32_t*)nullptr, (c->gen_pace_ns > 0 ? c->gen_pace_ns : 0) / 10);
+  if (const char* e = getenv("GOENV_GEN_MULTI_M")) {   // stamps of k_generate_pipe_multi with M boards per workgroup
+    const int m = atoi(e), grid = (((c->n + m - 1) / m + 7) / 8) * 8;
+    hipLaunchKernelGGL(k_generate_pipe_multi, dim3(grid), dim3(128), (size_t)m * sizeof(SavedBoard), S(stream), P, n_plies,
+                       (int32_t*)nullptr, (c->gen_pace_ns > 0 ? c->gen_pace_ns : 0) / 10);
+  } else if (c->gen_pipe > 0) hipLaunchKernelGGL(k_generate_pipe, dim3(c->n), dim3(128), 0, S(stream), P, n_plies, (int32_t*)nullptr, (c->gen_pace_ns > 0 ? c->gen_pace_ns : 0) / 10);
   else GO_LAUNCH(nw, k_generate, c->n, S(stream), P, n_plies, (int32_t*)nullptr);
   HIPCHK(hipGetLastError());
   return 0;
