@@ -773,7 +773,7 @@ __global__ __launch_bounds__(128) void k_generate_pipe(PlyParams P, int n_plies,
       gather_masks(L, g, o, m);
 #endif
       PTICK(1);
-      if (t >= PIPE_DEPTH) pipe_wait(&X.consumed, t - PIPE_DEPTH + 1);   // slot t % PIPE_DEPTH has been taken
+      if (t >= PIPE_DEPTH) pipe_wait(&X.consumed, t - PIPE_DEPTH + 1, P.stats + GOENV_NUM_STATS + 1);   // slot t % PIPE_DEPTH has been taken
       PTICK(2);
       snapshot_write(X.snap[t % PIPE_DEPTH], g, lab, lastp, s, o, a);
       pipe_post(&X.produced, t + 1, g.lane);
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(128) void k_generate_pipe(PlyParams P, int n_plies,
     unsigned long long next = wall_clock64();
     for (int t = 0; t < n_plies; ++t) {
       PTICK(0);
-      pipe_wait(&X.produced, t + 1);
+      pipe_wait(&X.produced, t + 1, P.stats + GOENV_NUM_STATS + 1);
       PTICK(1);
       SnapRegs r;
       snapshot_load(X.snap[t % PIPE_DEPTH], lane, src, r);
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_
         PTICK(2);
         lds_store_board(saved[i], g, lab, lastp, s, m);
         PTICK(3);
-        if (j >= PIPE_DEPTH) pipe_wait(&X.consumed, j - PIPE_DEPTH + 1);
+        if (j >= PIPE_DEPTH) pipe_wait(&X.consumed, j - PIPE_DEPTH + 1, P.stats + GOENV_NUM_STATS + 1);
         PTICK(4);
         PipeSnap& S = X.snap[j % PIPE_DEPTH];
         snapshot_write(S, g, lab, lastp, s, o, a);
@@ -916,7 +916,7 @@ __global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_
     int t = 0, i = 0;
     for (int j = 0; j < items; ++j) {
       PTICK(0);
-      pipe_wait(&X.produced, j + 1);
+      pipe_wait(&X.produced, j + 1, P.stats + GOENV_NUM_STATS + 1);
       PTICK(1);
       const PipeSnap& S = X.snap[j % PIPE_DEPTH];
       const int aug = __builtin_amdgcn_readfirstlane(S.aug), b = __builtin_amdgcn_readfirstlane(S.row);
@@ -2226,8 +2226,14 @@ int64_t* goenv_stats_ptr(goenv_ctx* c) { return c ? (int64_t*)c->stats : nullptr
 int goenv_stats_host(goenv_ctx* c, int64_t* out16_host, void* stream) {
   if (!c || !out16_host) return fail("goenv_stats_host: NULL argument");
   ON_DEVICE_OF(c);
-  HIPCHK(hipMemcpyAsync(out16_host, c->stats, GOENV_NUM_STATS * sizeof(int64_t), hipMemcpyDeviceToHost, S(stream)));
+  int64_t all[STATS_ALLOC];
+  HIPCHK(hipMemcpyAsync(all, c->stats, sizeof(all), hipMemcpyDeviceToHost, S(stream)));
   HIPCHK(hipStreamSynchronize(S(stream)));
+  memcpy(out16_host, all, GOENV_NUM_STATS * sizeof(int64_t));
+  // the word behind the scratch slot counts waits of the pipelined generator that ran into their bound (pipe_wait)
+  if (all[GOENV_NUM_STATS + 1] != 0)
+    return fail("goenv_stats_host: a wave of the pipelined generator gave up waiting for its partner (the rings of that launch "
+                "are not to be trusted); this does not happen on a healthy device");
   return 0;
 }
 

@@ -1006,13 +1006,18 @@ struct __attribute__((aligned(16))) PipeLds {
   int32_t produced, consumed;           // snapshots written by the rules wave / taken by the feature wave so far
 };
 
-// Wait (bounded: a wave always gets out) until the LDS counter has reached `want`.
-__device__ __forceinline__ void pipe_wait(const int32_t* counter, int want) {
+// Wait until the LDS counter has reached `want`.  Bounded, so that a wave always gets out: the two waves of a workgroup are
+// resident together and neither waits for anything else, so the bound (seconds) is never met on a healthy device; if it is,
+// the wave counts it into `stalls` (the word behind the context's statistics, which goenv_stats_host / goenv_finish turn
+// into an error) and goes on, so the grid drains.
+__device__ __forceinline__ void pipe_wait(const int32_t* counter, int want, unsigned long long* stalls) {
   int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-  for (int spin = 0; v < want && spin < (1 << 24); ++spin) {
+  int spin = 0;
+  for (; v < want && spin < (1 << 24); ++spin) {
     __builtin_amdgcn_s_sleep(2);
     v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
   }
+  if (v < want && stalls && (threadIdx.x & 63) == 0) atomicAdd(stalls, 1ull);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ __forceinline__ void pipe_post(int32_t* counter, int value, int lane) {

@@ -466,7 +466,10 @@ int goenv_tactics(goenv_ctx* ctx, const int32_t* idx, int first, int count, int 
  * add it to the device stats vector (boards keep their state).
  * goenv_stats_ptr: device int64[GOENV_NUM_STATS] -- this is the buffer a
  * multi-GPU job hands to RCCL all-reduce (torch.distributed).  goenv_stats_host
- * copies it to a host int64[16] (synchronises the stream). */
+ * copies it to a host int64[16] (synchronises the stream); it fails, after
+ * filling out16_host, if a wait inside the pipelined generator ever ran into
+ * its bound (a device-side counter behind the vector: never on a healthy
+ * device; the rings of such a launch are not to be trusted). */
 int goenv_finish(goenv_ctx* ctx, void* stream);
 int64_t* goenv_stats_ptr(goenv_ctx* ctx);
 int goenv_stats_host(goenv_ctx* ctx, int64_t* out16_host, void* stream);
