@@ -878,6 +878,8 @@ __global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_
     fill_rim(L, g.tid);
     wsync<1>();
     int j = 0;
+    SavedRegs fetched;
+    if (mine > 0) lds_fetch_board(saved[0], g, fetched);
     for (int t = 0; t < n_plies; ++t) {      // host-supplied bounds, the same for both waves
       for (int i = 0; i < mine; ++i, ++j) {
         const int b = board_at(i);
@@ -886,7 +888,7 @@ __global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_
         Masks m;
         Own<1> o;
         PTICK(0);
-        lds_load_board(saved[i], L, g, lab, lastp, s, m);
+        lds_load_board(fetched, L, g, lab, lastp, s, m);
         own_from_masks(g, m, o);
         PTICK(1);
         if (s.done) {
@@ -897,6 +899,7 @@ __global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_
         gather_masks(L, g, o, m);
         PTICK(2);
         lds_store_board(saved[i], g, lab, lastp, s, m);
+        lds_fetch_board(saved[i + 1 < mine ? i + 1 : 0], g, fetched);   // the next turn's board, under the hand-over below
         PTICK(3);
         if (j >= PIPE_DEPTH) pipe_wait(&X.consumed, j - PIPE_DEPTH + 1, P.stats + GOENV_NUM_STATS + 1);
         PTICK(4);

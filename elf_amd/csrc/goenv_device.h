@@ -1078,18 +1078,23 @@ static_assert(sizeof(SavedBoard) == sizeof(BoardRec) && offsetof(BoardRec, legal
                   offsetof(BoardRec, sc) == offsetof(SavedBoard, uni) + 24 * 4,
               "a saved board is a record with its two tables packed");
 
-// One wave; the label image's rim is the caller's.
-__device__ __forceinline__ void lds_load_board(const SavedBoard& R, BoardLds<1>& L, const Geo<1>& g, uint32_t lab[],
+// One wave; the label image's rim is the caller's.  In two steps, so that the reads of the NEXT board can be in flight while
+// the wave still finishes the current one: lds_fetch_board issues them, lds_load_board takes what they brought.
+struct SavedRegs { uint32_t raw[NWORDS]; int uni; };
+__device__ __forceinline__ void lds_fetch_board(const SavedBoard& R, const Geo<1>& g, SavedRegs& f) {
+  GO_UNROLL
+  for (int k = 0; k < NWORDS; ++k) f.raw[k] = g.p[k] < NPTS ? R.raw[g.p[k]] : 0u;
+  f.uni = (int)R.uni[g.lane < 40 ? g.lane : 0];
+}
+__device__ __forceinline__ void lds_load_board(const SavedRegs& f, BoardLds<1>& L, const Geo<1>& g, uint32_t lab[],
                                                uint32_t lastp[], Scalars& s, Masks& m) {
   GO_UNROLL
   for (int k = 0; k < NWORDS; ++k) {
-    const bool v = g.p[k] < NPTS;
-    const uint32_t r = v ? R.raw[g.p[k]] : 0u;
-    lab[k] = r & 0xffffu;
-    lastp[k] = r >> 16;
-    if (v) L.lab[g.c[k]] = (uint16_t)lab[k];
+    lab[k] = f.raw[k] & 0xffffu;
+    lastp[k] = f.raw[k] >> 16;
+    if (g.p[k] < NPTS) L.lab[g.c[k]] = (uint16_t)lab[k];
   }
-  const int mine = (int)R.uni[g.lane < 40 ? g.lane : 0];
+  const int mine = f.uni;
   int u[40];
   GO_UNROLL
   for (int i = 0; i < 40; ++i) u[i] = __builtin_amdgcn_readlane(mine, i);
