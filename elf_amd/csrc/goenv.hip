@@ -763,7 +763,10 @@ __global__ __launch_bounds__(128) void k_generate_pipe(PlyParams P, int n_plies,
     PTICK(0);
     // the rules wave goes before the feature waves that share its SIMD: its chain is the dependent one, theirs waits for the
     // store queue anyway (512 boards: 5.9 -> 5.3 us per ply, 1,024: -2 %, 4,096: -4 %; profiles/r03_pipe_generator.md)
-    __builtin_amdgcn_s_setprio(3);
+    // (up to five workgroups per CU; with six the feature waves need their turns: 1,536 boards 11.9 -> 12.5 us per ply)
+#ifndef GOENV_NO_RULES_PRIO
+    if (gridDim.x <= 1280) __builtin_amdgcn_s_setprio(3);
+#endif
     for (int t = 0; t < n_plies; ++t) {  // host-supplied bound, the same for both waves
 #if GOENV_PIPE_ABLATE == 2   // probe: no rules (the feature wave and the store stream alone)
       const int a = -1;
@@ -883,7 +886,9 @@ __global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_
     int j = 0;
     SavedRegs fetched;
     if (mine > 0) lds_fetch_board(saved[0], g, fetched);
+#ifndef GOENV_NO_RULES_PRIO
     __builtin_amdgcn_s_setprio(3);   // as in k_generate_pipe
+#endif
     for (int t = 0; t < n_plies; ++t) {      // host-supplied bounds, the same for both waves
       for (int i = 0; i < mine; ++i, ++j) {
         const int b = board_at(i);
