@@ -4,8 +4,8 @@
 // The offered store rate that the memory side takes best differs from card to card by a few per cent (cliff measured at
 // 6.0 .. 6.5 ns per board-ply), and offering more than that costs 10 % (profiles/r03_pipe_generator.md).  goenv_generate
 // times its own launches (events recorded around the kernel, read back later without waiting) and moves between a few
-// candidate paces: every candidate twice in turn, then the best one by a running estimate, with a neighbour tried every
-// sixteenth launch because a card's state drifts.  The pace changes WHEN samples are written, never what is written.
+// candidate paces: every candidate twice in turn, then the best one by a running estimate -- re-timed every sixteenth launch,
+// a neighbour tried every sixteenth because a card's state drifts, the other launches untimed.  The pace changes WHEN samples are written, never what is written.
 #pragma once
 
 struct GenTuneCore {
@@ -36,6 +36,14 @@ struct GenTuneCore {
       if (nb >= 0 && nb < NC) return nb;
     }
     return b;
+  }
+  // Whether the next launch is to be timed.  An event after a kernel costs the stream a system-scope release (about 25 us per
+  // launch at 1,024 boards: 0.2 us per ply of a 128-ply launch), so once every candidate has been tried only one launch in
+  // eight is timed: alternately the best candidate and, every sixteenth launch, the neighbour that pick() probes.
+  bool want_timing() const {
+    for (int i = 0; i < NC; ++i)
+      if (launched[i] < 2) return true;
+    return launches % 8 == 7;
   }
   // a launch with candidate c has been enqueued (timed: its duration will be reported by result())
   void enqueued(int c, bool timed) {

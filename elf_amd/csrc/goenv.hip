@@ -731,6 +731,11 @@ __global__ __launch_bounds__(64 * NW) void k_generate(PlyParams P, int n_plies, 
 #ifndef GOENV_PIPE_ABLATE
 #define GOENV_PIPE_ABLATE 0
 #endif
+#ifndef GOENV_PACE_RESET
+// periods a feature wave may fall behind its schedule before the schedule starts over.  It catches up by leaving waits out, so that
+// all boards end a launch together (2 periods: 6.57 us per ply at a pinned 6.4 us; 16: 6.48; profiles/r03_pipe_generator.md section 14)
+#define GOENV_PACE_RESET 16
+#endif
 // The same generator as a two-stage pipeline INSIDE the board's workgroup (goenv_device.h, PipeSnap): wave 0 plays ply
 // t + 1 while wave 1 writes the sample of ply t.  Same ring contents, bit for bit.
 __global__ __launch_bounds__(128) void k_generate_pipe(PlyParams P, int n_plies, int32_t* actions_ring, int pace_ticks) {
@@ -814,7 +819,7 @@ __global__ __launch_bounds__(128) void k_generate_pipe(PlyParams P, int n_plies,
           now = wall_clock64();
         }
         // a fixed schedule, so that a sample that started late does not delay those after it; dropped after a long gap
-        next = (now > next + 2ull * (unsigned long long)pace_ticks) ? now + (unsigned long long)pace_ticks
+        next = (now > next + (unsigned long long)GOENV_PACE_RESET * (unsigned long long)pace_ticks) ? now + (unsigned long long)pace_ticks
                                                                      : next + (unsigned long long)pace_ticks;
       }
       PTICK(3);
@@ -949,7 +954,7 @@ __global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_
           __builtin_amdgcn_s_sleep(1);
           now = wall_clock64();
         }
-        next = (now > next + 2ull * (unsigned long long)period) ? now + (unsigned long long)period
+        next = (now > next + (unsigned long long)GOENV_PACE_RESET * (unsigned long long)period) ? now + (unsigned long long)period
                                                                  : next + (unsigned long long)period;
       }
       PTICK(3);
@@ -2170,7 +2175,7 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
       }
       gen_tune_collect(t);
       cand = t.pick();
-      for (int i = 0; i < GenTune::NPEND && !timed; ++i)
+      for (int i = 0; i < GenTune::NPEND && !timed && t.want_timing(); ++i)
         if (!t.pend[i].busy) timed = &t.pend[i];
       if (timed) { timed->cand = cand; timed->plies = n_plies; }
       t.enqueued(cand, timed != nullptr);

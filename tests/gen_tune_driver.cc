@@ -31,8 +31,9 @@ int main(int argc, char** argv) {
     const int c = t.pick();
     const double pace = GenTuneCore::cand[c];
     const double cost = (pace < cliff ? cliff * 1.10 + (cliff - pace) : pace) * 1.024 * noise(permille) + 0.3;   // us per ply at 1,024 boards
-    t.enqueued(c, true);
-    in_flight.push_back({c, cost});
+    const bool timed = t.want_timing();
+    t.enqueued(c, timed);
+    if (timed) in_flight.push_back({c, cost});
     if (i >= launches - launches / 4) { used[c] += 1; tail_cost += cost; tail_n += 1; }
   }
   for (int c = 0; c < GenTuneCore::NC; ++c) printf("%d ", used[c]);
