@@ -9,10 +9,11 @@
 #pragma once
 
 struct GenTuneCore {
-  static constexpr int NC = 6;
-  // ns per board-ply offered: 36,465 B / 6.75 ns = 5.40 TB/s is the safe side of every cliff seen
-  static constexpr float cand[NC] = {6.10f, 6.25f, 6.40f, 6.55f, 6.75f, 7.10f};
-  static constexpr int SAFE = 4;
+  static constexpr int NC = 9;
+  // ns per board-ply offered, finer where the cliffs have been seen (6.05 .. 6.5): 36,465 B / 6.80 ns = 5.36 TB/s is the safe
+  // side of all of them
+  static constexpr float cand[NC] = {6.00f, 6.10f, 6.18f, 6.25f, 6.33f, 6.40f, 6.55f, 6.80f, 7.20f};
+  static constexpr int SAFE = 7;
   float est[NC];          // us per ply, running estimate (valid where samples > 0)
   int samples[NC], launched[NC];
   int launches;

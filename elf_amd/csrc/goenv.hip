@@ -1273,6 +1273,7 @@ static size_t g_lds_pad = getenv("GOENV_LDS_PAD") ? (size_t)atoi(getenv("GOENV_L
 // host side
 // ----------------------------------------------------------------------------------------------
 
+static_assert(GenTuneCore::NC == GOENV_GEN_PACE_CANDIDATES, "include/goenv.h: size of goenv_generate_pace's est_out");
 // the tuner's logic (gen_tune.h) + the events of launches whose time has not been read back yet
 struct GenTune : GenTuneCore {
   static constexpr int NPEND = 8;
@@ -2199,7 +2200,7 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
 }
 
 // What the generator's self-tuning rate limiter has settled on: ns per board-ply offered (0: not in use or no result
-// yet), its estimates per candidate in est_out[6] (us per ply, 0 = none), and whether the last goenv_generate went through
+// yet), its estimates per candidate in est_out[GOENV_GEN_PACE_CANDIDATES] (us per ply, 0 = none), and whether the last goenv_generate went through
 // the pipelined kernel.  Diagnostic.
 int goenv_generate_pace(goenv_ctx* c, float* pace_ns_per_board_out, float* est_out, int* pipelined_out) {
   if (!c) return fail("goenv_generate_pace: ctx is NULL");

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(HERE, "libgoenv.so")
 NUM_POINTS = 361
 NUM_PLANES = 25
 FEAT_FLOATS = NUM_PLANES * NUM_POINTS
+GEN_PACE_CANDIDATES = 9       # GOENV_GEN_PACE_CANDIDATES, include/goenv.h
 NUM_STATS = 16
 REC_BYTES = 1632
 PASS = -1
@@ -424,7 +425,7 @@ class GoEnv:
     def generate_pace(self):
         """goenv_generate_pace: (ns per board-ply that the generator's rate limiter has settled on, [us per ply per
         candidate pace])."""
-        pace, est = C.c_float(0), (C.c_float * 6)()
+        pace, est = C.c_float(0), (C.c_float * GEN_PACE_CANDIDATES)()
         self._chk(self.lib.goenv_generate_pace(self._h, C.byref(pace), est, None))
         return pace.value, list(est)
 

@@ -412,13 +412,14 @@ int goenv_generate(goenv_ctx* ctx, int n_plies, const int32_t* aug_codes, float*
 /* goenv_generate_pace (diagnostic): with all boards resident on the device, goenv_generate
  * rate-limits its plane stores and tunes that rate by timing its own launches (events, never
  * a wait).  pace_ns_per_board_out: the pace it has settled on, in ns per board-ply (0: none
- * yet / not in use); est_out: float[6] or NULL, its time estimates per candidate pace in us
+ * yet / not in use); est_out: float[GOENV_GEN_PACE_CANDIDATES] or NULL, its time estimates per candidate pace in us
  * per ply (0 = not measured); pipelined_out: 1 if the last goenv_generate of this context
  * went through the pipelined kernel (k_generate_pipe), 0 if through k_generate.  Any may be
  * NULL.  The pace changes when samples are written, never their bytes.
  * GOENV_GEN_PACE_NS=<ns between two samples of a board> pins it (0 = no limiter),
  * GOENV_GEN_PIPE=0 selects the non-pipelined generator kernel.  No counterpart in the
  * reference. */
+#define GOENV_GEN_PACE_CANDIDATES 9
 int goenv_generate_pace(goenv_ctx* ctx, float* pace_ns_per_board_out, float* est_out,
                         int* pipelined_out);
 
