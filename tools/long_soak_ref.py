@@ -7,7 +7,7 @@ for millions of board-plies, through the three paths that write planes:
   k_ply<.,2>  the fused selfplay step (move sampled from a reply pi)         (B boards x PLIES / 2)
   k_generate_pipe        the bench line's kernel, rings of T plies           (1,024 boards x 64 plies x LAUNCHES)
   k_generate_pipe_multi  several boards per workgroup, D4 codes 0..7         (4,096 boards x 16 plies x LAUNCHES / 2)
-Usage: tools/long_soak_ref.py [boards] [plies] [generator launches]"""
+Usage: tools/long_soak_ref.py [boards] [plies] [generator launches] [seed]"""
 import os
 import sys
 import time
@@ -23,7 +23,7 @@ from oracle.pyoracle import RefBatch  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 PLIES = int(sys.argv[2]) if len(sys.argv) > 2 else 800
 LAUNCHES = int(sys.argv[3]) if len(sys.argv) > 3 else 40
-seed, cap = 91, 722
+seed, cap = (int(sys.argv[4]) if len(sys.argv) > 4 else 91), 722
 t0 = time.time()
 total = 0
 
@@ -60,7 +60,7 @@ ref = RefBatch(B)
 feat, legal, acts, status = env.new(torch.float32, 25, 19, 19), env.new(torch.uint8, 361), env.new(torch.int32), env.new(torch.int32)
 zero = np.zeros(B, np.int32)
 g = torch.Generator(device=env.device)
-g.manual_seed(7)
+g.manual_seed(7 + seed)
 E = goenv.F_RESET_ILLEGAL | goenv.F_RESTART_AFTER_END
 restarts = 0
 for t in range(PLIES // 2):
