@@ -329,7 +329,7 @@ def extra_measurements(goenv, seed):
     fr = torch.empty(T, B, 25, 19, 19, device=env.device)
     lr = torch.empty(T, B, 361, dtype=torch.uint8, device=env.device)
     ar = torch.empty(T, B, dtype=torch.int32, device=env.device)
-    for _ in range(16):                       # the generator's rate limiter walks through its candidate paces first
+    for _ in range(2 * goenv.GEN_PACE_CANDIDATES + 6):   # the generator's rate limiter walks through its candidate paces first
         env.generate(T, fr, lr, ar)
     torch.cuda.synchronize()
     env.timer_begin()

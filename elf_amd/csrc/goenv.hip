@@ -1273,6 +1273,11 @@ static size_t g_lds_pad = getenv("GOENV_LDS_PAD") ? (size_t)atoi(getenv("GOENV_L
 // host side
 // ----------------------------------------------------------------------------------------------
 
+// plane outputs of the last launches (planes_in_flight below)
+constexpr int OUT_SEEN = 16;
+constexpr size_t WRITE_THROUGH_MAX_BYTES = 160u << 20;   // 4,096 boards' planes are 141 MiB
+struct OutSeen { const void* p; size_t bytes; uint64_t when; };
+
 static_assert(GenTuneCore::NC == GOENV_GEN_PACE_CANDIDATES, "include/goenv.h: size of goenv_generate_pace's est_out");
 // the tuner's logic (gen_tune.h) + the events of launches whose time has not been read back yet
 struct GenTune : GenTuneCore {
@@ -1318,6 +1323,8 @@ struct goenv_ctx {
   int gen_last_pipe;                   // the last goenv_generate went through k_generate_pipe (1) / _multi (2)
   int gen_multi_m, gen_multi_grid;     // k_generate_pipe_multi: boards per workgroup (0: not asked yet, -1: none fits), grid
   GenTune tune;
+  OutSeen out_seen[OUT_SEEN];          // plane outputs of the last launches (planes_in_flight)
+  uint64_t out_clock;
 };
 
 // The standalone feature kernel has no rules phase that staggers its waves' stores: mid-size
@@ -1330,18 +1337,43 @@ static int pick_nw_features(const goenv_ctx* c, int count) {
   return 3;
 }
 
+// Bytes of planes that the last OUT_SEEN launches wrote to DISTINCT buffers, this launch included: what has to stay in the
+// 256-MB Infinity Cache for write-through plane stores to pay.  A caller that writes every step's planes to the same batch
+// tensor (the collectors of a GameContext) keeps one entry; one that rotates through a ring of outputs, or steps the batch
+// in parts, adds them up (tools/time_parts_ring.py: 4,096 boards into a ring of eight buffers 61 us per ply with
+// write-through stores, 34 us with plain ones; 8,192 boards as two parts 89 -> 56 us).
+static size_t planes_in_flight(goenv_ctx* c, const float* feat, int count) {
+  const uint64_t now = ++c->out_clock;
+  int slot = -1, oldest = 0;
+  for (int i = 0; i < OUT_SEEN; ++i) {
+    if (c->out_seen[i].p == feat) slot = i;
+    if (c->out_seen[i].when < c->out_seen[oldest].when) oldest = i;
+  }
+  if (slot < 0) slot = oldest;
+  c->out_seen[slot].p = feat;
+  c->out_seen[slot].bytes = (size_t)count * GOENV_FEAT_FLOATS * sizeof(float);
+  c->out_seen[slot].when = now;
+  size_t sum = 0;
+  for (int i = 0; i < OUT_SEEN; ++i)
+    if (c->out_seen[i].p && now - c->out_seen[i].when < (uint64_t)OUT_SEEN) sum += c->out_seen[i].bytes;
+  return sum;
+}
+
 // How the planes are stored: bit 0 = the 11 constant planes first (tuning knob, no gain
 // measured), bit 1 = write-through (`sc1`) plane stores.  Write-through pays for launches whose
 // whole output fits the caches (no end-of-kernel write-back of tens of MB: 13.2 -> 12.1 us at
 // 1,024 boards) and costs 1.5x on an HBM-sized stream, so it is used for launches of up to 4,096 boards.
-static int pick_zero_first(const goenv_ctx* c, int count) {
-  // bit 2 (+ bit 0: write_features then skips them too): the caller keeps the 11 constant planes zero itself
-  if (c->planes_preset) return ((c->zero_first >= 0 ? c->zero_first : (count <= 4096 ? 2 : 0)) & 2) | 5;
-  if (c->zero_first >= 0) return c->zero_first;
+static int pick_zero_first(goenv_ctx* c, int count, const float* feat_out) {
   // tools/tune_waves.py under GOENV_ZERO_FIRST=0 / 2: write-through wins up to 6,144 boards (16.5 -> 14.6 us at
   // 1,536, 18.8 -> 17.0 at 2,048, 31.5 -> 30.5 at 4,096, 42.9 -> 42.4 at 6,144) and loses badly once a ply's planes
-  // no longer fit the 256-MB Infinity Cache (8,192 boards = 296 MB: 57 -> 89 us)
-  return count <= 4096 ? 2 : 0;
+  // no longer fit the 256-MB Infinity Cache (8,192 boards = 296 MB: 57 -> 89 us) -- or the planes of the last few
+  // launches together, when they go to different buffers (planes_in_flight)
+  bool through = count <= 4096;
+  if (feat_out && planes_in_flight(c, feat_out, count) > WRITE_THROUGH_MAX_BYTES) through = false;
+  // bit 2 (+ bit 0: write_features then skips them too): the caller keeps the 11 constant planes zero itself
+  if (c->planes_preset) return ((c->zero_first >= 0 ? c->zero_first : (through ? 2 : 0)) & 2) | 5;
+  if (c->zero_first >= 0) return c->zero_first;
+  return through ? 2 : 0;
 }
 
 // Waves per board of a launch over `count` boards.  Small launches are bound by the dependent
@@ -1564,7 +1596,7 @@ static PlyParams make_params(goenv_ctx* c, uint32_t flags, const int64_t* action
   P.seed = c->seed; P.id_base = c->id_base; P.komi = c->komi; P.max_ply = c->max_ply;
   P.stamps = nullptr;
   P.lut1 = c->lut1;
-  P.zero_first = pick_zero_first(c, c->n);
+  P.zero_first = pick_zero_first(c, c->n, nullptr);
   P.xcd_map = c->xcd_map;
   return P;
 }
@@ -1597,7 +1629,7 @@ static int ply_sel_impl(goenv_ctx* c, const char* who, const int32_t* idx, int f
   PlyParams P = make_params(c, flags, actions, aug_codes, feat_out, legal_out, actions_out, status_out);
   P.n = count; P.idx = idx; P.first = first;
   P.pi = pi; P.pi_aug = pi_aug;
-  P.zero_first = pick_zero_first(c, count);
+  P.zero_first = pick_zero_first(c, count, feat_out);
   if (meta) P.meta = *meta;
   GO_LAUNCH_PLY(pick_nw(c, count), mode, count, S(stream), P);
   HIPCHK(hipGetLastError());
@@ -1737,7 +1769,7 @@ int goenv_collect_sel(goenv_ctx* c, const int32_t* idx, int first, int count, co
   const int nw = pick_nw_features(c, count);
   const size_t lds_pad = g_lds_pad ? g_lds_pad : ((count >= 16384 && nw == 3 && feat_out) ? 16000 : 0);
   GO_LAUNCH_LDS(nw, k_features, count, lds_pad, S(stream), c->state, c->n, idx, first, count, aug_codes, c->lut,
-                feat_out, legal_out, m, meta ? 1 : 0, c->lut1, pick_zero_first(c, count), c->xcd_map);
+                feat_out, legal_out, m, meta ? 1 : 0, c->lut1, pick_zero_first(c, count, feat_out), c->xcd_map);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2007,7 +2039,7 @@ int goenv_offline_batch(goenv_ctx* c, const void* block, int count, int k_future
   PlyParams P = make_params(c, 0u, nullptr, nullptr, feat_out, legal_out, nullptr, nullptr);
   P.n = count;
   P.max_ply = 0;  // a replayed record is not subject to the playout ply cap
-  P.zero_first = pick_zero_first(c, count);
+  P.zero_first = pick_zero_first(c, count, feat_out);
   if (labels) P.meta = *labels;
   const int nw = feat_out ? pick_nw_features(c, count) : pick_nw(c, count);
   GO_LAUNCH(nw, k_offline, count, S(stream), P, (const int32_t*)block, row_w, k_future,

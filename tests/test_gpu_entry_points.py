@@ -423,3 +423,25 @@ def test_offline_batch_through_the_c_abi(goenv, device_block):
     with pytest.raises(goenv.GoEnvError, match="past the end"):
         env.offline_batch(ptr, 1, k, off)
     env.close()
+
+
+@pytest.mark.gpu
+def test_rotating_outputs_same_planes_as_one_buffer(goenv):
+    """Launches of up to 4,096 boards store their planes write-through while what the last launches wrote fits the
+    Infinity Cache, and with plain stores once a caller rotates through more output than that (planes_in_flight in
+    goenv.hip): 640 boards into one buffer against 640 boards into a ring of eight (185 MB) -- the same bytes."""
+    B, R = 640, 8
+    flags = goenv.F_RANDOM_POLICY | goenv.F_AUTO_RESTART
+    a, b = goenv.GoEnv(B, seed=5, max_ply=722), goenv.GoEnv(B, seed=5, max_ply=722)
+    one, one_legal = a.new(torch.float32, 25, 19, 19), a.new(torch.uint8, 361)
+    ring = torch.zeros(R, B, 25, 19, 19, device=b.device)
+    ring_legal = torch.zeros(R, B, 361, dtype=torch.uint8, device=b.device)
+    for t in range(40):
+        a.ply(flags, feat_out=one, legal_out=one_legal)
+        b.ply(flags, feat_out=ring[t % R], legal_out=ring_legal[t % R])
+        assert torch.equal(one.view(torch.int32), ring[t % R].view(torch.int32)), "ply %d" % t
+        assert torch.equal(one_legal, ring_legal[t % R])
+    sa, sb = a.get_state(), b.get_state()
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    a.close()
+    b.close()
