@@ -46,6 +46,17 @@ struct GenTuneCore {
       if (launched[i] < 2) return true;
     return launches % 8 == 7;
   }
+  // The candidate of the next launch and whether it is to be timed.  slot_free: an event pair is available.  A burst of
+  // launches can outrun the events (their results come back only when the first launches have finished): a launch that
+  // should be timed and cannot be teaches nothing, so it runs at the best pace known so far instead of an untried one.
+  int next(bool slot_free, bool& timed) const {
+    timed = want_timing() && slot_free;
+    if (want_timing() && !slot_free) {
+      const int b = best();
+      return b < 0 ? SAFE : b;
+    }
+    return pick();
+  }
   // a launch with candidate c has been enqueued (timed: its duration will be reported by result())
   void enqueued(int c, bool timed) {
     if (timed) launched[c] += 1;

@@ -2121,14 +2121,18 @@ int goenv_playout(goenv_ctx* c, int16_t* moves_out, int max_record, int32_t* nmo
 
 // results of timed launches that have finished (never waits)
 static void gen_tune_collect(GenTune& t) {
+  bool not_ready = false;
   for (int i = 0; i < GenTune::NPEND; ++i) {
     GenTune::Pend& p = t.pend[i];
-    if (!p.busy || hipEventQuery(p.e1) != hipSuccess) continue;
+    if (!p.busy) continue;
+    const hipError_t q = hipEventQuery(p.e1);
+    if (q == hipErrorNotReady) { not_ready = true; continue; }
+    if (q != hipSuccess) continue;                 // a real error: left for the caller's next checked call to report
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess && ms > 0.f) t.result(p.cand, ms * 1e3f / (float)p.plies);
     p.busy = 0;
   }
-  (void)hipGetLastError();   // hipEventQuery reports "not ready" as an error
+  if (not_ready) (void)hipGetLastError();   // hipEventQuery leaves "not ready" behind as the last error: that one is ours
 }
 
 int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* feat_ring, uint8_t* legal_ring,
@@ -2207,10 +2211,12 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
         t.events_ready = 1;
       }
       gen_tune_collect(t);
-      cand = t.pick();
-      for (int i = 0; i < GenTune::NPEND && !timed && t.want_timing(); ++i)
-        if (!t.pend[i].busy) timed = &t.pend[i];
-      if (timed) { timed->cand = cand; timed->plies = n_plies; }
+      GenTune::Pend* slot = nullptr;
+      for (int i = 0; i < GenTune::NPEND && !slot; ++i)
+        if (!t.pend[i].busy) slot = &t.pend[i];
+      bool want = false;
+      cand = t.next(slot != nullptr, want);
+      if (want) { timed = slot; timed->cand = cand; timed->plies = n_plies; }
       t.enqueued(cand, timed != nullptr);
     } else if (t.best() >= 0) {
       cand = t.best();

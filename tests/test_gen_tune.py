@@ -53,3 +53,12 @@ def test_follows_a_cliff_that_moves(driver):
     want = first_above(6.2)
     assert best == want, (used, best)
     assert used[want] >= 0.85 * sum(used), used
+
+
+def test_a_burst_that_outruns_the_events(driver):
+    """Results 20 launches late, 8 event pairs: launches that cannot be timed run at the best pace known so far (the safe one
+    before any result), never at an untried candidate; the walk finishes all the same."""
+    used, best, mean = run(driver, 6.3, 1200, 5, 20, -1, 6.3, 8)
+    want = first_above(6.3)
+    assert best == want, (used, best)
+    assert used[want] >= 0.9 * sum(used), used
