@@ -357,7 +357,7 @@ def extra_measurements(goenv, seed):
     res["cfg5_selfplay_fp32"] = cfg5_selfplay(["--num_games", "1024", "--batchsize", "1024", "--iters", "15"])
     res["cfg5_selfplay_bf16"] = cfg5_selfplay(["--num_games", "2048", "--batchsize", "2048", "--iters", "15", "--bf16"])
     # the rules-only step kernel (k_playout: whole games with the board in LDS/registers, no planes) -- the
-    # LDS/VALU-bound half of the path; its counters against gfx950 peaks: profiles/r03_playout.md
+    # LDS/VALU-bound half of the path; its counters against gfx950 peaks: profiles/r03_playout.md, r03b_playout.md
     for B in (1024, 8192, 65536):
         env = goenv.GoEnv(B, seed=seed, max_ply=722)
         nm = env.new(torch.int32)

@@ -1386,6 +1386,22 @@ static int pick_nw(const goenv_ctx* c, int count) {
   return 3;
 }
 
+// Launches that write no planes (goenv_step, goenv_playout, goenv_replay, the moves of tree-search leaves, an offline batch
+// without `s`) have no store stream for several waves to share; once the device is full they are bound by instruction
+// issue, and one wave per board issues least (no barriers, the scalar mask arithmetic once instead of once per wave).
+// Measured (tools/playout_prof.py, tools/time_rules_waves.py; 1 / 2 / 3 waves): whole playouts 65,536 boards 763 / 607 /
+// 482 M moves/s, 8,192 boards 587 / 515 / 438, 4,096 boards 495 / 459 / 384, 3,072 boards 444 / 443 / 365, 2,048 boards
+// 343 / 381 / 347, 1,536 boards 261 / 292 / 305, 1,024 boards 210 / 264 / 266; one rules-only ply per launch 65,536 boards
+// 185 / 191 / 234 us, 8,192 boards 28.6 / 29.6 / 34.3, 4,096 boards 16.4 / 17.4 / 19.6, 2,048 boards 12.0 / 10.9 / 11.4,
+// 1,024 boards 10.5 / 8.4 / 8.2.
+static int pick_nw_rules(const goenv_ctx* c, int count) {
+  if (c->nw) return c->nw;
+  if (count <= 512) return 6;
+  if (count <= 1536) return 3;
+  if (count < 3072) return 2;
+  return 1;
+}
+
 // the stats vector is followed by one scratch word (the MAX slot travels through it in
 // goenv_stats_allreduce)
 constexpr int STATS_ALLOC = GOENV_NUM_STATS + 2;
@@ -1631,7 +1647,7 @@ static int ply_sel_impl(goenv_ctx* c, const char* who, const int32_t* idx, int f
   P.pi = pi; P.pi_aug = pi_aug;
   P.zero_first = pick_zero_first(c, count, feat_out);
   if (meta) P.meta = *meta;
-  GO_LAUNCH_PLY(pick_nw(c, count), mode, count, S(stream), P);
+  GO_LAUNCH_PLY(feat_out ? pick_nw(c, count) : pick_nw_rules(c, count), mode, count, S(stream), P);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1972,7 +1988,7 @@ int goenv_replay(goenv_ctx* c, const int32_t* idx, int first, int count, const i
   PlyParams P = make_params(c, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   P.n = count; P.idx = idx; P.first = first;
   P.max_ply = 0;  // a replayed record is not subject to the playout ply cap
-  GO_LAUNCH(pick_nw(c, count), k_replay, count, S(stream), P, moves, stride, nmoves, napplied_out);
+  GO_LAUNCH(pick_nw_rules(c, count), k_replay, count, S(stream), P, moves, stride, nmoves, napplied_out);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2041,7 +2057,7 @@ int goenv_offline_batch(goenv_ctx* c, const void* block, int count, int k_future
   P.max_ply = 0;  // a replayed record is not subject to the playout ply cap
   P.zero_first = pick_zero_first(c, count, feat_out);
   if (labels) P.meta = *labels;
-  const int nw = feat_out ? pick_nw_features(c, count) : pick_nw(c, count);
+  const int nw = feat_out ? pick_nw_features(c, count) : pick_nw_rules(c, count);
   GO_LAUNCH(nw, k_offline, count, S(stream), P, (const int32_t*)block, row_w, k_future,
             (const int16_t*)((const char*)block + moves_offset), offline_a_out, c->bad_moves);
   HIPCHK(hipGetLastError());
@@ -2114,7 +2130,7 @@ int goenv_playout(goenv_ctx* c, int16_t* moves_out, int max_record, int32_t* nmo
   if (c->max_ply <= 0) return fail("goenv_playout: the context needs a ply cap (max_ply > 0)");
   if (moves_out && max_record <= 0) return fail("goenv_playout: max_record must be positive");
   PlyParams P = make_params(c, GOENV_F_RANDOM_POLICY, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-  GO_LAUNCH(pick_nw(c, c->n), k_playout, c->n, S(stream), P, moves_out, max_record, nmoves_out);
+  GO_LAUNCH(pick_nw_rules(c, c->n), k_playout, c->n, S(stream), P, moves_out, max_record, nmoves_out);
   HIPCHK(hipGetLastError());
   return 0;
 }

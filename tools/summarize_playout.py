@@ -110,15 +110,17 @@ def main():
         f.write("; ".join("%d boards: %.0f VALU, %.0f SALU, %.0f LDS instructions, %.0f LDS-array cycles, %.1f of 64 lanes active per VALU instruction"
                           % (o["boards"], o["per_board_ply"]["valu"], o["per_board_ply"]["salu"], o["per_board_ply"]["lds"],
                              o["per_board_ply"]["lds_array_cycles"], o["per_board_ply"]["active_lanes_per_valu"] or 0) for o in rows))
-        f.write(".\n\nReading: the kernel is bound by instruction ISSUE and by the latency of one board's dependent chain, not by "
-                "a memory system: at full occupancy (65,536 boards) 37 % of the wave cycles are parked on `s_waitcnt` / barriers, 37 % "
-                "wait for an issue slot and 26 % issue; the vector pipe issues at 35 % of its peak rate (69 % by the gfx94x `VALUBusy` "
-                "formula, which prices an instruction at 4 cycles), the LDS array is busy a third of the time with a tenth of that "
-                "lost to bank conflicts, and there are MORE scalar than vector instructions (the 361-bit masks live in scalar "
-                "registers: ballots, popcounts, 64-bit mixes of the counter RNG).  The guide documents no scalar issue peak; under "
-                "the classic one-issue-turn-per-SIMD-every-fourth-cycle model (an inference, not a measured constant) 0.25 scalar "
-                "instructions per SIMD-cycle would be the ceiling and the kernel sits at 0.19 of it at 65,536 boards.  At 1,024 boards the "
-                "launch is 2.2 waves per SIMD of a possible 7.5 (3,072 waves on 1,024 SIMDs): occupancy, i.e. the batch size, is the limit.\n")
+        f.write(".\n")
+        if all(o["waves_per_board"] == 3 for o in rows):   # the reading below was written for the three-wave launches of r03
+            f.write("\nReading: the kernel is bound by instruction ISSUE and by the latency of one board's dependent chain, not by "
+                    "a memory system: at full occupancy (65,536 boards) 37 % of the wave cycles are parked on `s_waitcnt` / barriers, 37 % "
+                    "wait for an issue slot and 26 % issue; the vector pipe issues at 35 % of its peak rate (69 % by the gfx94x `VALUBusy` "
+                    "formula, which prices an instruction at 4 cycles), the LDS array is busy a third of the time with a tenth of that "
+                    "lost to bank conflicts, and there are MORE scalar than vector instructions (the 361-bit masks live in scalar "
+                    "registers: ballots, popcounts, 64-bit mixes of the counter RNG).  The guide documents no scalar issue peak; under "
+                    "the classic one-issue-turn-per-SIMD-every-fourth-cycle model (an inference, not a measured constant) 0.25 scalar "
+                    "instructions per SIMD-cycle would be the ceiling and the kernel sits at 0.19 of it at 65,536 boards.  At 1,024 boards the "
+                    "launch is 2.2 waves per SIMD of a possible 7.5 (3,072 waves on 1,024 SIMDs): occupancy, i.e. the batch size, is the limit.\n")
     print(open(os.path.join(prof, rnd + "_playout.md")).read())
 
 
