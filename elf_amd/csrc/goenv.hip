@@ -1382,7 +1382,9 @@ static int pick_zero_first(goenv_ctx* c, int count, const float* feat_out) {
 // stores of a board (65,536 boards: 585 us with two waves, 492 us with three).
 static int pick_nw(const goenv_ctx* c, int count) {
   if (c->nw) return c->nw;   // measured: tools/tune_waves.py, profiles/r01_tune_waves.txt
-  if (count <= 512) return 6;
+  // six waves while every board has a CU to itself (256 boards: 8.0 us against 8.9 with three); from 384 boards on three
+  // (384: 9.7 against 10.0 with six, 512: 9.95 against 10.1; whole playouts 1.37 against 1.54 ms)
+  if (count <= 256) return 6;
   return 3;
 }
 
@@ -1396,7 +1398,7 @@ static int pick_nw(const goenv_ctx* c, int count) {
 // 1,024 boards 10.5 / 8.4 / 8.2.
 static int pick_nw_rules(const goenv_ctx* c, int count) {
   if (c->nw) return c->nw;
-  if (count <= 512) return 6;
+  if (count <= 256) return 6;
   if (count <= 1536) return 3;
   if (count < 3072) return 2;
   return 1;
