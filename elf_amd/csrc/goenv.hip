@@ -435,10 +435,11 @@ __global__ __launch_bounds__(64 * NW) void k_features(BoardRec* state, int n_tot
 // integer arithmetic (weights floor(pi * 2^24)), keyed by the counter RNG; all-zero weights fall
 // back to the cfg-2 random policy.  pi is indexed in the augmented frame of aug_codes[b].
 // One wavefront per board (reads only the record's masks; no board image needed).
-__global__ __launch_bounds__(64) void k_sample_policy(const BoardRec* state, int n_total, const int32_t* idx,
+constexpr int SAMPLER_WAVES = 4;   // boards per workgroup: the waves share nothing, fewer workgroups to dispatch
+__global__ __launch_bounds__(64 * SAMPLER_WAVES) void k_sample_policy(const BoardRec* state, int n_total, const int32_t* idx,
                                                       int first, int n, const float* pi, const int32_t* aug_codes,
                                                       int64_t* actions_out, uint64_t seed, int64_t id_base) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+  const int b = blockIdx.x * SAMPLER_WAVES + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (b >= n) return;
   const int board = board_of(idx, first, n_total, b);
   if (board < 0) {
@@ -1639,7 +1640,7 @@ static int ply_sel_impl(goenv_ctx* c, const char* who, const int32_t* idx, int f
   if (mode == 2 && count > c->fuse_max) {
     // large selections: the sampler as a launch of its own (one wave per board, all resident at once),
     // then the ply kernel on the sampled moves -- same moves, same outputs as the fused kernel
-    hipLaunchKernelGGL(k_sample_policy, dim3(count), dim3(64), 0, S(stream), c->state, c->n, idx, first, count, pi,
+    hipLaunchKernelGGL(k_sample_policy, dim3((count + SAMPLER_WAVES - 1) / SAMPLER_WAVES), dim3(64 * SAMPLER_WAVES), 0, S(stream), c->state, c->n, idx, first, count, pi,
                        pi_aug, c->sampled, c->seed, c->id_base);
     HIPCHK(hipGetLastError());
     actions = c->sampled; pi = nullptr; pi_aug = nullptr; mode = 0;
@@ -1904,7 +1905,7 @@ int goenv_sample_policy(goenv_ctx* c, const int32_t* idx, int first, int count, 
   ON_DEVICE_OF(c);
   if (!pi || !actions_out) return fail("goenv_sample_policy: pi and actions_out are required");
   if (count == 0) return 0;
-  hipLaunchKernelGGL(k_sample_policy, dim3(count), dim3(64), 0, S(stream), c->state, c->n, idx, first, count, pi,
+  hipLaunchKernelGGL(k_sample_policy, dim3((count + SAMPLER_WAVES - 1) / SAMPLER_WAVES), dim3(64 * SAMPLER_WAVES), 0, S(stream), c->state, c->n, idx, first, count, pi,
                      aug_codes, actions_out, c->seed, c->id_base);
   HIPCHK(hipGetLastError());
   return 0;
