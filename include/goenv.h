@@ -151,7 +151,8 @@ int goenv_create(int device, int n_boards, uint64_t seed, int64_t board_id_base,
 int goenv_destroy(goenv_ctx* ctx);
 int goenv_num_boards(const goenv_ctx* ctx);
 /* Launch shape: wavefronts that share one board (1, 2, 3 or 6; 0 = chosen per launch from the
- * batch size, the default).  Results do not depend on it.  No counterpart in the reference. */
+ * batch size and from whether the launch writes planes, the default).  Results do not depend
+ * on it.  No counterpart in the reference. */
 int goenv_set_waves_per_board(goenv_ctx* ctx, int nw);
 /* goenv_get_fuse_max: the largest selection that goenv_ply_policy_sel steps in ONE launch (above
  * it the sampler is a launch of its own; 3,072 unless GOENV_FUSE_MAX is set).  No counterpart in the
