@@ -1396,7 +1396,7 @@ static int pick_nw(const goenv_ctx* c, int count) {
 // 482 M moves/s, 8,192 boards 587 / 515 / 438, 4,096 boards 495 / 459 / 384, 3,072 boards 444 / 443 / 365, 2,048 boards
 // 343 / 381 / 347, 1,536 boards 261 / 292 / 305, 1,024 boards 210 / 264 / 266; one rules-only ply per launch 65,536 boards
 // 185 / 191 / 234 us, 8,192 boards 28.6 / 29.6 / 34.3, 4,096 boards 16.4 / 17.4 / 19.6, 2,048 boards 12.0 / 10.9 / 11.4,
-// 1,024 boards 10.5 / 8.4 / 8.2.
+// 1,024 boards 10.5 / 8.4 / 8.2; goenv_score 65,536 boards 108 / 117 / 142 us, 16,384 boards 34 / 34 / 39 (tools/time_score_waves.py).
 static int pick_nw_rules(const goenv_ctx* c, int count) {
   if (c->nw) return c->nw;
   if (count <= 256) return 6;
@@ -2274,7 +2274,7 @@ int goenv_generate_pace(goenv_ctx* c, float* pace_ns_per_board_out, float* est_o
 int goenv_score(goenv_ctx* c, float* score_out, float* fast_out, void* stream) {
   if (!c) return fail("goenv_score: ctx is NULL");
   ON_DEVICE_OF(c);
-  GO_LAUNCH(pick_nw(c, c->n), k_score, c->n, S(stream), c->state, c->n, score_out, fast_out, 0);
+  GO_LAUNCH(pick_nw_rules(c, c->n), k_score, c->n, S(stream), c->state, c->n, score_out, fast_out, 0);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2283,7 +2283,7 @@ int goenv_fast_score(goenv_ctx* c, int rule, float* out, void* stream) {
   if (!c || !out) return fail("goenv_fast_score: NULL argument");
   ON_DEVICE_OF(c);
   if (rule != 0 && rule != 1) return fail("goenv_fast_score: rule must be 0 (Chinese) or 1 (Japanese)");
-  GO_LAUNCH(pick_nw(c, c->n), k_score, c->n, S(stream), c->state, c->n, (float*)nullptr, out, rule);
+  GO_LAUNCH(pick_nw_rules(c, c->n), k_score, c->n, S(stream), c->state, c->n, (float*)nullptr, out, rule);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2291,7 +2291,7 @@ int goenv_fast_score(goenv_ctx* c, int rule, float* out, void* stream) {
 int goenv_finish(goenv_ctx* c, void* stream) {
   if (!c) return fail("goenv_finish: ctx is NULL");
   ON_DEVICE_OF(c);
-  GO_LAUNCH(pick_nw(c, c->n), k_finish, c->n, S(stream), c->state, c->n, c->stats, c->komi);
+  GO_LAUNCH(pick_nw_rules(c, c->n), k_finish, c->n, S(stream), c->state, c->n, c->stats, c->komi);
   HIPCHK(hipGetLastError());
   return 0;
 }
