@@ -824,7 +824,7 @@ __global__ __launch_bounds__(128) void k_generate_pipe(PlyParams P, int n_plies,
                                                                      : next + (unsigned long long)pace_ticks;
       }
       PTICK(3);
-      const size_t row = (size_t)t * P.n + b;
+      const size_t row = (size_t)t * P.n_total + P.first + b;   // (P.first: a launch over a part of the boards, as in the _multi kernel)
       if (actions_ring && lane == 0) actions_ring[row] = r.action;
       uint8_t* lg = P.legal ? P.legal + row * NPTS : nullptr;
 #if GOENV_PIPE_ABLATE == 1   // probe: no samples written (the rules wave alone)
@@ -959,7 +959,9 @@ __global__ __launch_bounds__(128) void k_generate_pipe_multi(PlyParams P, int n_
                                                                  : next + (unsigned long long)period;
       }
       PTICK(3);
-      const size_t row = (size_t)t * n + b;
+      // (a launch over a part of the context's boards -- goenv_generate in chunks -- has P.state, P.aug and P.id_base moved to
+      // its first board; a slot of the rings holds all P.n_total boards)
+      const size_t row = (size_t)t * P.n_total + P.first + b;
       if (actions_ring && lane == 0) actions_ring[row] = r.action;
       uint8_t* lg = P.legal ? P.legal + row * NPTS : nullptr;
       if (P.feat) {
@@ -1323,6 +1325,9 @@ struct goenv_ctx {
   int wall_khz;                        // rate of the wall clock that the rate limiter reads (s_memrealtime: 100 MHz on gfx950)
   int gen_last_pipe;                   // the last goenv_generate went through k_generate_pipe (1) / _multi (2)
   int gen_multi_m, gen_multi_grid;     // k_generate_pipe_multi: boards per workgroup (0: not asked yet, -1: none fits), grid
+  int gen_chunk_n;                     // more boards than k_generate_pipe_multi holds: launches over this many boards each, one after
+  int gen_last_m, gen_last_grid;       // the other (0: the whole context in one launch); the shape of the last, shorter one
+  int gen_chunk_min_plies;             // ... for launches of at least this many plies (8; GOENV_GEN_CHUNK_MIN_PLIES), else k_generate
   GenTune tune;
   OutSeen out_seen[OUT_SEEN];          // plane outputs of the last launches (planes_in_flight)
   uint64_t out_clock;
@@ -2138,6 +2143,29 @@ int goenv_playout(goenv_ctx* c, int16_t* moves_out, int max_record, int32_t* nmo
   return 0;
 }
 
+// The cheapest launch shape of the pipelined generator over n boards by the cost model described in goenv_generate:
+// m = 1 is k_generate_pipe, 2 .. 16 boards per workgroup k_generate_pipe_multi, -1 = none fits; cost in ns per ply.
+struct GenShape { int m, grid; double cost; };
+static int gen_shape(goenv_ctx* c, int n, int cus, GenShape* out) {
+  out->m = -1; out->grid = 0; out->cost = 0;
+  int forced = 0;
+  if (const char* e = getenv("GOENV_GEN_MULTI_M")) forced = atoi(e);   // tuning only
+  for (int m = 1; m <= 16; ++m) {
+    if (forced && m != forced) continue;
+    const int grid = m == 1 ? n : (((n + m - 1) / m + 7) / 8) * 8;
+    int per_cu = 0;
+    if (m == 1) per_cu = c->gen_resident > 0 ? c->gen_resident / (cus > 0 ? cus : 1) : 0;
+    else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_generate_pipe_multi, 128, (size_t)m * sizeof(SavedBoard)));
+    if (grid > per_cu * cus || (m > 1 && !forced && grid > 4 * cus)) continue;
+    const int k = (grid + cus - 1) / cus;                               // workgroups on the fullest CU
+    const double imbalance = (double)k * cus / grid;
+    double cost = n * (k <= 4 ? 6.5 : 6.9) * imbalance;                 // ns per ply, store side
+    if (m > 1 && cost < m * 6900.0) cost = m * 6900.0;                  // rules side
+    if (out->m < 0 || cost < out->cost) { out->m = m; out->grid = grid; out->cost = cost; }
+  }
+  return 0;
+}
+
 // results of timed launches that have finished (never waits)
 static void gen_tune_collect(GenTune& t) {
   bool not_ready = false;
@@ -2180,31 +2208,39 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
   // in LDS; -1 = neither fits).  Measured (profiles/r03_pipe_generator.md, section 11): the memory side takes the plane stream
   // best from about 1,024 storing waves -- four workgroups on every CU, one wave pair per SIMD -- at 6.5 ns per board-ply;
   // from five to eight workgroups per CU it takes 6.9; an uneven number per CU costs its imbalance; and a rules wave needs
-  // 6.9 us for a board's turn.  The cheapest of the shapes that fit:
+  // 6.9 us for a board's turn.  The cheapest of the shapes that fit (gen_shape).  More boards than any shape holds go through
+  // the same kernel in CHUNKS, one launch after the other on the stream, each over a contiguous part of the boards and its
+  // rows of every ring slot (boards are independent: the same rings): 16,384 boards as 2 x 8,192, 65,536 as 8 x 8,192.
   if (!c->gen_multi_m) {
     int cus = 0;
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-    double best_cost = 0;
-    c->gen_multi_m = -1;
-    int forced = 0;
-    if (const char* e = getenv("GOENV_GEN_MULTI_M")) forced = atoi(e);   // tuning only
-    for (int m = 1; m <= 16; ++m) {
-      if (forced && m != forced) continue;
-      const int grid = m == 1 ? c->n : (((c->n + m - 1) / m + 7) / 8) * 8;
-      int per_cu = 0;
-      if (m == 1) per_cu = c->gen_resident > 0 ? c->gen_resident / (cus > 0 ? cus : 1) : 0;
-      else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_generate_pipe_multi, 128, (size_t)m * sizeof(SavedBoard)));
-      if (grid > per_cu * cus || (m > 1 && !forced && grid > 4 * cus)) continue;
-      const int k = (grid + cus - 1) / cus;                               // workgroups on the fullest CU
-      const double imbalance = (double)k * cus / grid;
-      double cost = c->n * (k <= 4 ? 6.5 : 6.9) * imbalance;              // ns per ply, store side
-      if (m > 1 && cost < m * 6900.0) cost = m * 6900.0;                  // rules side
-      if (c->gen_multi_m < 0 || cost < best_cost) { c->gen_multi_m = m; c->gen_multi_grid = grid; best_cost = cost; }
+    GenShape whole;
+    if (gen_shape(c, c->n, cus, &whole)) return -1;
+    c->gen_multi_m = whole.m; c->gen_multi_grid = whole.grid; c->gen_chunk_n = 0;
+    // (a launch boundary costs a chunk what it costs any launch of the kernel: 16,384 boards x 8 plies per launch 124 -> 113 us
+    // per ply, 32,768 boards 244 -> 223, but 65,536 boards x 4 plies 478 -> 490: shorter launches stay with k_generate)
+    c->gen_chunk_min_plies = 8;
+    if (const char* e = getenv("GOENV_GEN_CHUNK_MIN_PLIES")) c->gen_chunk_min_plies = atoi(e);
+    if (whole.m < 0 && !getenv("GOENV_GEN_NO_CHUNKS")) {
+      double best = 0;
+      for (int k = 2; k <= 256 && c->n / k >= 1024; ++k) {
+        const int chunk = (((c->n + k - 1) / k + 7) / 8) * 8, last = c->n - (k - 1) * chunk;
+        if (last <= 0) continue;
+        GenShape a, b;
+        if (gen_shape(c, chunk, cus, &a) || gen_shape(c, last, cus, &b)) return -1;
+        if (a.m < 2 || b.m < 1) continue;
+        const double cost = (k - 1) * a.cost + b.cost;
+        if (!c->gen_chunk_n || cost < best) {
+          best = cost;
+          c->gen_chunk_n = chunk; c->gen_multi_m = a.m; c->gen_multi_grid = a.grid; c->gen_last_m = b.m; c->gen_last_grid = b.grid;
+        }
+      }
     }
   }
   const bool resident = c->gen_multi_m == 1;
-  const bool multi = c->gen_multi_m > 1 && !c->nw && c->gen_pipe != 0;
-  const bool pipe = c->nw ? false : (c->gen_pipe < 0 ? (resident || multi) : c->gen_pipe != 0);
+  const bool multi = c->gen_multi_m > 1 && !c->nw && c->gen_pipe != 0 && !(c->gen_chunk_n && n_plies < c->gen_chunk_min_plies);
+  // (GOENV_GEN_PIPE=1 with no shape that fits, chunks turned off: k_generate_pipe over all boards, in rounds, unpaced -- a probe)
+  const bool pipe = !c->nw && c->gen_pipe != 0 && (resident || multi || (c->gen_pipe > 0 && c->gen_multi_m < 0));
   c->gen_last_pipe = pipe ? (multi ? 2 : 1) : 0;
   if (!pipe) {
     const int nw = c->nw ? c->nw : (c->n <= 4096 ? 2 : 3);
@@ -2213,6 +2249,7 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
     return 0;
   }
   int pace_ticks = 0;   // ticks of the wall clock (10 ns)
+  float pace_per_board = 0.f;   // tuned: ns per board-ply
   GenTune::Pend* timed = nullptr;
   if (c->gen_pace_ns >= 0) {
     pace_ticks = (resident || multi) ? (int)((double)c->gen_pace_ns * c->wall_khz * 1e-6) : 0;
@@ -2240,14 +2277,25 @@ int goenv_generate(goenv_ctx* c, int n_plies, const int32_t* aug_codes, float* f
     } else if (t.best() >= 0) {
       cand = t.best();
     }
-    pace_ticks = (int)((double)GenTune::cand[cand] * c->n * c->wall_khz * 1e-6);
+    pace_per_board = GenTune::cand[cand];
   }
   if (timed) HIPCHK(hipEventRecord(timed->e0, S(stream)));
-  if (multi)   // pace_ticks: the time of one ply of ALL boards; a workgroup divides it by its boards
-    hipLaunchKernelGGL(k_generate_pipe_multi, dim3(c->gen_multi_grid), dim3(128), (size_t)c->gen_multi_m * sizeof(SavedBoard),
-                       S(stream), P, n_plies, actions_ring, pace_ticks);
-  else
-    hipLaunchKernelGGL(k_generate_pipe, dim3(c->n), dim3(128), 0, S(stream), P, n_plies, actions_ring, pace_ticks);
+  const int chunks = c->gen_chunk_n ? (c->n + c->gen_chunk_n - 1) / c->gen_chunk_n : 1;
+  for (int k = 0; k < chunks; ++k) {
+    const int first = k * c->gen_chunk_n, count = chunks == 1 ? c->n : (c->n - first < c->gen_chunk_n ? c->n - first : c->gen_chunk_n);
+    const bool tail = chunks > 1 && k == chunks - 1;
+    const int m = tail ? c->gen_last_m : c->gen_multi_m, grid = tail ? c->gen_last_grid : c->gen_multi_grid;
+    PlyParams Q = P;   // this launch's boards: rows first .. first + count of every ring slot
+    Q.n = count; Q.first = first; Q.state = P.state + first; Q.id_base = P.id_base + first;
+    if (Q.aug) Q.aug += first;
+    // the tuned pace is per board-ply: the period of one ply of the boards of THIS launch
+    const int ticks = pace_per_board > 0.f ? (int)((double)pace_per_board * count * c->wall_khz * 1e-6) : pace_ticks;
+    if (m > 1)   // ticks: the time of one ply of all its boards; a workgroup divides it by the boards it holds
+      hipLaunchKernelGGL(k_generate_pipe_multi, dim3(grid), dim3(128), (size_t)m * sizeof(SavedBoard), S(stream), Q, n_plies,
+                         actions_ring, ticks);
+    else
+      hipLaunchKernelGGL(k_generate_pipe, dim3(count), dim3(128), 0, S(stream), Q, n_plies, actions_ring, ticks);
+  }
   HIPCHK(hipGetLastError());
   if (timed) {
     HIPCHK(hipEventRecord(timed->e1, S(stream)));

@@ -54,9 +54,13 @@ def same(x, y):
                                           (300, 23, "fla", True),
                                           # more boards than resident workgroups: several boards per workgroup, waiting
                                           # in LDS (k_generate_pipe_multi), ragged last turn
-                                          (2500, 5, "fla", True), (4100, 3, "fl", False), (8200, 2, "fla", True)])
+                                          (2500, 5, "fla", True), (4100, 3, "fl", False), (8200, 2, "fla", True),
+                                          # more boards than that kernel holds: launches over chunks of the boards, one
+                                          # after the other (16,500 = 3 x 5,504: the last one shorter; 20,000: 3 x 6,672)
+                                          (16500, 2, "fla", True), (20000, 1, "fl", False)])
 def test_pipelined_equals_two_wave_kernel(goenv, monkeypatch, n, T, what, aug):
     out = []
+    monkeypatch.setenv("GOENV_GEN_CHUNK_MIN_PLIES", "1")     # (by default launches of fewer than 8 plies are not cut into chunks)
     for pipe in (False, True):
         env = make(goenv, monkeypatch, pipe, n, seed=5, max_ply=80 if n < 2000 else 12)
         augs = ((torch.arange(n, dtype=torch.int32, device=env.device) * 3) % 8).contiguous() if aug else None
@@ -76,6 +80,27 @@ def test_pipelined_equals_two_wave_kernel(goenv, monkeypatch, n, T, what, aug):
     for i, (x, y) in enumerate(zip(*out)):
         assert same(x, y), (i, n, T, what)
     assert int(out[0][-1][goenv.ST_GAMES]) > 0 or T * 6 < 80
+
+
+def test_chunks_only_for_launches_of_eight_plies(goenv, monkeypatch):
+    """More boards than k_generate_pipe_multi holds: launches of at least 8 plies go through it in chunks, shorter ones through
+    k_generate (a launch boundary costs every chunk); the same rings either way."""
+    n = 16500
+    monkeypatch.delenv("GOENV_GEN_CHUNK_MIN_PLIES", raising=False)
+    a, b = make(goenv, monkeypatch, True, n, seed=9, max_ply=20), make(goenv, monkeypatch, False, n, seed=9, max_ply=20)
+    for T, kernel in ((2, "k_generate"), (8, "k_generate_pipe_multi"), (3, "k_generate")):
+        ra, rb = rings(a, T, "fla", None), rings(b, T, "fla", None)
+        a.generate(T, *ra)
+        b.generate(T, *rb)
+        torch.cuda.synchronize()
+        assert a.generate_kernel() == kernel and b.generate_kernel() == "k_generate"
+        for x, y in zip(ra, rb):
+            assert same(x, y), T
+        del ra, rb
+    sa, sb = a.get_state(), b.get_state()
+    assert all(same(sa[k], sb[k]) for k in sa)
+    a.close()
+    b.close()
 
 
 def test_pipelined_rings_against_the_oracle(goenv, monkeypatch):
