@@ -323,26 +323,27 @@ def extra_measurements(goenv, seed):
         res["launch_per_ply_%d" % B] = r
         env.close()
         del feat, legal
-    # generator at the cfg-4 shard: 16 plies per launch (4.7 GB of planes per launch)
-    B, T = 8192, 16
-    env = goenv.GoEnv(B, seed=seed, max_ply=722)
-    fr = torch.empty(T, B, 25, 19, 19, device=env.device)
-    lr = torch.empty(T, B, 361, dtype=torch.uint8, device=env.device)
-    ar = torch.empty(T, B, dtype=torch.int32, device=env.device)
-    for _ in range(2 * goenv.GEN_PACE_CANDIDATES + 6):   # the generator's rate limiter walks through its candidate paces first
-        env.generate(T, fr, lr, ar)
-    torch.cuda.synchronize()
-    env.timer_begin()
-    for _ in range(10):
-        env.generate(T, fr, lr, ar)
-    env.timer_end()
-    ms = env.timer_ms() / (10 * T)
-    res["generate_8192"] = {"ply_ms": ms, "moves_per_s": B / (ms * 1e-3), "plies_per_launch": T,
-                            "GBps": B * ALG_BYTES_PER_BOARD_PLY / (ms * 1e-3) / 1e9, "kernel": env.generate_kernel(),
-                            "store_pace_ns_per_board_ply": env.generate_pace()[0]}
-    env.close()
-    del fr, lr, ar
-    torch.cuda.empty_cache()
+    # generator at the cfg-4 shard: 16 plies per launch (4.7 GB of planes per launch); and over 65,536 boards, 8 plies per
+    # launch (19 GB): more boards than one launch of the pipelined kernel holds, cut into chunks of 8,192
+    for B, T in ((8192, 16), (65536, 8)):
+        env = goenv.GoEnv(B, seed=seed, max_ply=722)
+        fr = torch.empty(T, B, 25, 19, 19, device=env.device)
+        lr = torch.empty(T, B, 361, dtype=torch.uint8, device=env.device)
+        ar = torch.empty(T, B, dtype=torch.int32, device=env.device)
+        for _ in range(2 * goenv.GEN_PACE_CANDIDATES + 6):   # the generator's rate limiter walks through its candidate paces first
+            env.generate(T, fr, lr, ar)
+        torch.cuda.synchronize()
+        env.timer_begin()
+        for _ in range(10):
+            env.generate(T, fr, lr, ar)
+        env.timer_end()
+        ms = env.timer_ms() / (10 * T)
+        res["generate_%d" % B] = {"ply_ms": ms, "moves_per_s": B / (ms * 1e-3), "plies_per_launch": T,
+                                  "GBps": B * ALG_BYTES_PER_BOARD_PLY / (ms * 1e-3) / 1e9, "kernel": env.generate_kernel(),
+                                  "store_pace_ns_per_board_ply": env.generate_pace()[0]}
+        env.close()
+        del fr, lr, ar
+        torch.cuda.empty_cache()
     # the API path the north star names: GameContext selfplay, Wait -> reply pi on the device -> Steps
     for B in (1024, 8192):
         res["game_context_selfplay_%d" % B] = game_context_selfplay(B, seed, True)
