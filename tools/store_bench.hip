@@ -9,6 +9,7 @@
 //   mode 3  plane splits between two waves of a board      mode 4  one storing wave per group of boards
 //   mode 5  stream expanders from packed samples           mode 6  alignment of the wave-stores
 //   mode 7  cache-policy bits of the stores (sc0 / sc1 / nt)     mode 8  samples written in address order in time
+//   mode 10 paced stores: rows padded to whole cache lines / written as aligned 1-KB stores
 //   mode 9  paced stores: rows per XCD / per CU / ring[b][t] / half samples / two waves
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -707,6 +708,65 @@ static void run_paced(float* out, int n, int T, int reps) {
       fflush(stdout);
     }
 }
+// mode 10: do partial cache lines matter?  A sample is 36,100 B, so rows of a ring slot start at every offset mod 128 and the line at
+// each row boundary is written by two workgroups.  Paced stores as in mode 9 var 0 (rows per XCD, hashed phases) with
+// var 0: the product's layout (row stride 9,025 floats)            1: rows padded to 9,056 floats (283 whole lines), same stores
+// var 2: padded rows, written as a flat run of aligned 1-KB stores  3: the product's stride, flat run of 1-KB stores (unaligned)
+__global__ __launch_bounds__(64) void p_paced_align(float* out, int n, int T, int var, int period_ns, unsigned long long* t0p) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const int b = (w & 7) * (n >> 3) + (w >> 3);
+  const size_t stride = (var == 1 || var == 2) ? 9056 : FB;
+  const unsigned long long now = wall_clock64();
+  if (lane == 0) atomicMin(t0p, now);
+  __builtin_amdgcn_s_sleep(127);
+  unsigned long long t0 = __hip_atomic_load(t0p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 3000;
+  t0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(t0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)t0);
+  const long long off_ns = (long long)(((unsigned)b * 40503u) % (unsigned)n) * period_ns / n;
+  for (int t = 0; t < T; ++t) {
+    float* o = out + ((size_t)t * n + b) * stride;
+    const unsigned long long target = t0 + (unsigned long long)(((long long)t * period_ns + off_ns) / 10);
+    for (int spin = 0; spin < (1 << 20) && wall_clock64() < target; ++spin) __builtin_amdgcn_s_sleep(1);
+    if (var < 2) {
+      for (int pl = 0; pl < 25; ++pl) {
+        float v = (float)(pl + t);
+        uf4 val = {v, v + 1, v + 2, v + 3};
+        *(uf4*)(o + pl * NP + 4 * lane) = val;
+        if (lane < 26) *(uf4*)(o + pl * NP + 256 + 4 * lane) = val;
+        if (lane == 26) o[pl * NP + 360] = v;
+      }
+    } else {
+      for (int k = 0; k < 35; ++k) {             // 35 x 256 floats = 8,960, then the tail of 65 floats
+        float v = (float)(k + t);
+        uf4 val = {v, v + 1, v + 2, v + 3};
+        *(uf4*)(o + k * 256 + 4 * lane) = val;
+      }
+      if (lane < 16) { uf4 val = {1.f, 2.f, 3.f, 4.f}; *(uf4*)(o + 8960 + 4 * lane) = val; }
+      if (lane == 16) o[9024] = 5.f;
+    }
+  }
+}
+static void run_paced_align(float* out, int n, int T, int reps) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  unsigned long long* t0p; hipMalloc(&t0p, 8);
+  const int periods[7] = {5600, 5800, 5900, 6000, 6100, 6200, 6400};
+  for (int var = 0; var < 4; ++var)
+    for (int pi = 0; pi < 7; ++pi) {
+      const int period = (int)((long long)periods[pi] * n / 1024);
+      float tot = 0;
+      for (int r = 0; r < reps + 1; ++r) {
+        hipMemsetAsync(t0p, 0xff, 8, 0);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(p_paced_align, dim3(n), dim3(64), 0, 0, out, n, T, var, period, t0p);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (r) tot += ms;
+      }
+      float ms = tot / reps - 0.030f;
+      printf("n=%d T=%d align var %d period %5d ns  %8.3f us per ply  %7.1f GB/s (of 36,100-B samples)\n", n, T, var, period, ms * 1e3 / T,
+             (double)n * T * FB * 4 / (ms * 1e-3) / 1e9);
+      fflush(stdout);
+    }
+}
 static void run_front(float* out, int n, int T, int reps) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int nbp = n * T;
@@ -742,7 +802,8 @@ int main(int argc, char** argv) {
   const int T = argc > 3 ? atoi(argv[3]) : 0;   // > 0: the persistent variants only
   const int front = argc > 4 ? atoi(argv[4]) : 0; // 1: the two-stage (expander) probes over n*T board-plies
   float* out;
-  if (hipMalloc(&out, (size_t)n * (T > 0 ? T : 1) * FB * 4 + 64) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+  if (hipMalloc(&out, (size_t)n * (T > 0 ? T : 1) * (front == 10 ? 9056 : FB) * 4 + 256) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+  if (front == 10) { run_paced_align(out, n, T, reps); return 0; }
   if (front == 9) { run_paced(out, n, T, reps); return 0; }
   if (front == 8) { run_stagger(out, n, T, reps); return 0; }
   if (front == 7) { run_pol(out, n, T, reps); return 0; }
