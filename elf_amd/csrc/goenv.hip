@@ -1276,6 +1276,8 @@ static size_t g_lds_pad = getenv("GOENV_LDS_PAD") ? (size_t)atoi(getenv("GOENV_L
 // host side
 // ----------------------------------------------------------------------------------------------
 
+constexpr int STAGE_GROUP = 4;   // staging ring: blocks per event (stage_commit)
+static_assert(GOENV_STAGE_SLOTS % STAGE_GROUP == 0 && GOENV_STAGE_SLOTS >= 2 * STAGE_GROUP, "staging ring: whole groups, at least two");
 // plane outputs of the last launches (planes_in_flight below)
 constexpr int OUT_SEEN = 16;
 constexpr size_t WRITE_THROUGH_MAX_BYTES = 160u << 20;   // 4,096 boards' planes are 141 MiB
@@ -1313,7 +1315,9 @@ struct goenv_ctx {
   void* stage_host[GOENV_STAGE_SLOTS];
   size_t stage_cap[GOENV_STAGE_SLOTS];
   hipEvent_t stage_event[GOENV_STAGE_SLOTS];
-  int stage_busy[GOENV_STAGE_SLOTS];   // an event has been recorded after the slot's last reader
+  int stage_busy[GOENV_STAGE_SLOTS];   // handed to a kernel since it was acquired last
+  int stage_recorded[GOENV_STAGE_SLOTS];   // ... and stage_event[i] has been recorded behind that kernel
+  void* stage_stream[GOENV_STAGE_SLOTS];   // the stream of that kernel
   int stage_next;
   int32_t* bad_moves;                  // device counter of goenv_offline_batch rows that hit a rejected move
   int planes_preset;                   // goenv_set_constant_planes_preset
@@ -2010,7 +2014,12 @@ int goenv_stage_acquire(goenv_ctx* c, size_t bytes, void** host_block) {
   ON_DEVICE_OF(c);
   const int i = c->stage_next;
   if (c->stage_busy[i]) {   // the kernel that read this block last (GOENV_STAGE_SLOTS launches ago)
-    HIPCHK(hipEventSynchronize(c->stage_event[i]));
+    // the event behind it: its own, or the one recorded behind a later block of its group on the same stream (stage_commit)
+    int j = i;
+    const int end = i | (STAGE_GROUP - 1);
+    while (j <= end && !(c->stage_recorded[j] && c->stage_stream[j] == c->stage_stream[i])) ++j;
+    if (j <= end) HIPCHK(hipEventSynchronize(c->stage_event[j]));
+    else HIPCHK(hipDeviceSynchronize());   // (a group cut short: not reached while blocks are committed in ring order)
     c->stage_busy[i] = 0;
   }
   if (c->stage_cap[i] < bytes) {
@@ -2025,12 +2034,22 @@ int goenv_stage_acquire(goenv_ctx* c, size_t bytes, void** host_block) {
   return 0;
 }
 
-// marks the block acquired last as read by everything enqueued on `stream` so far
+// Marks the block acquired last as read by everything enqueued on `stream` so far.  An event behind a kernel costs the stream
+// a release of its own (the generator's tuner found 25 us behind a long kernel), so only every STAGE_GROUP-th block gets one:
+// streams run in order, and the event behind block i also says that the readers of the blocks before it on that stream are done.
+// A block whose successor goes to another stream gets its event then.
 static int stage_commit(goenv_ctx* c, const void* block, void* stream) {
   const int i = c->stage_next;
   if (block != c->stage_host[i]) return 0;   // not a ring block (device memory, or the caller's own)
-  HIPCHK(hipEventRecord(c->stage_event[i], S(stream)));
-  c->stage_busy[i] = 1;
+  c->stage_stream[i] = stream; c->stage_busy[i] = 1; c->stage_recorded[i] = 0;
+  if (i % STAGE_GROUP != 0 && c->stage_busy[i - 1] && !c->stage_recorded[i - 1] && c->stage_stream[i - 1] != stream) {
+    HIPCHK(hipEventRecord(c->stage_event[i - 1], S(c->stage_stream[i - 1])));
+    c->stage_recorded[i - 1] = 1;
+  }
+  if (i % STAGE_GROUP == STAGE_GROUP - 1) {
+    HIPCHK(hipEventRecord(c->stage_event[i], S(stream)));
+    c->stage_recorded[i] = 1;
+  }
   c->stage_next = (i + 1) % GOENV_STAGE_SLOTS;
   return 0;
 }

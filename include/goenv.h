@@ -350,7 +350,7 @@ int goenv_replay(goenv_ctx* ctx, const int32_t* idx, int first, int count, const
  * goenv_stage_acquire: the next block of a ring of GOENV_STAGE_SLOTS pinned host blocks of at least
  * `bytes` bytes (host pointer; waits until the launch that read this block last has finished).  The
  * block is taken by the next goenv_offline_batch call that is given it. */
-#define GOENV_STAGE_SLOTS 8
+#define GOENV_STAGE_SLOTS 16
 #define GOENV_MAX_FUTURE 16
 int goenv_stage_acquire(goenv_ctx* ctx, size_t bytes, void** host_block);
 int goenv_offline_batch(goenv_ctx* ctx, const void* block, int count, int k_future, size_t moves_offset,
