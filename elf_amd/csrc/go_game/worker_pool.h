@@ -13,17 +13,24 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h>
+
 namespace gogame {
 
 class WorkerPool {
  public:
-  // threads = 0: GOENV_HOST_THREADS if set, else min(8, hardware threads); 1 = run inline
+  // threads = 0: GOENV_HOST_THREADS if set, else min(16, the CPUs this process may run on); 1 = run inline
+  // (tree search, 256 games x 16 search threads on a 16-CPU share: 4 / 8 / 12 / 16 threads 1.46 / 1.89 / 2.14 / 2.30 M leaf
+  // evaluations per second)
   explicit WorkerPool(int threads = 0) {
     if (threads <= 0) {
       if (const char* e = std::getenv("GOENV_HOST_THREADS")) threads = std::atoi(e);
       if (threads <= 0) {
-        const unsigned hw = std::thread::hardware_concurrency();
-        threads = (int)(hw ? (hw < 8u ? hw : 8u) : 1u);
+        unsigned hw = std::thread::hardware_concurrency();
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) hw = (unsigned)CPU_COUNT(&set);
+        threads = (int)(hw ? (hw < 16u ? hw : 16u) : 1u);
       }
     }
     if (threads > 64) threads = 64;
