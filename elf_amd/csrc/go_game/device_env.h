@@ -46,6 +46,34 @@ class DevBuf {
   goenv_ctx* ctx_ = nullptr;
 };
 
+// Pinned host memory that kernels read and write IN PLACE (hipHostMalloc: one address for host and device): small index and
+// result arrays of a batch travel without a copy call.  The owner orders its own reuse (a stream synchronise between a
+// kernel that uses the block and the host's next write / read of it).
+class PinBuf {
+ public:
+  PinBuf() = default;
+  PinBuf(const PinBuf&) = delete;
+  PinBuf& operator=(const PinBuf&) = delete;
+  ~PinBuf() { release(); }
+  void ensure(size_t bytes) {
+    if (bytes <= cap_) return;
+    release();
+    const size_t cap = bytes < 4096 ? 4096 : bytes + bytes / 2;
+    chk(goenv_host_alloc(cap, &p_), "goenv_host_alloc");
+    cap_ = cap;
+  }
+  void release() {
+    if (p_) goenv_host_free(p_);
+    p_ = nullptr;
+    cap_ = 0;
+  }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p_); }
+
+ private:
+  void* p_ = nullptr;
+  size_t cap_ = 0;
+};
+
 // The boards of one GameContext on one GPU.
 class DeviceEnv {
  public:

@@ -180,6 +180,7 @@ struct Collector {
   std::vector<int> games;      // games parked in the outstanding batch
   std::vector<int> boards;     // their boards (row order)
   bool contiguous = false;     // boards are first, first+1, ...
+  bool idx_pinned = false;     // ... or listed in pin_idx (a tree-search leaf batch) instead of idx
   long batches = 0, samples = 0;
   // selfplay with device tensors: Steps() already wrote the NEXT samples of `games` into the input
   // tensors (one fused launch); the next Wait() only hands the batch out
@@ -187,7 +188,11 @@ struct Collector {
   uint64_t prefill_stamp = 0;
   // device staging
   DevBuf idx, aug, actions, status, stage_s, stage_legal, stage_meta[8], stage_pi;
+  // tree search: the index arrays of a leaf batch and its top-k / value results, read and written by the kernels in place
+  // (every leaf batch ends with a stream synchronise in Steps(), so the collector's next batch may overwrite them)
+  PinBuf pin_idx, pin_src, pin_dst, pin_act, pin_topa, pin_topp, pin_v;
   void release_buffers() {
+    for (PinBuf* b : {&pin_idx, &pin_src, &pin_dst, &pin_act, &pin_topa, &pin_topp, &pin_v}) b->release();
     idx.release(); aug.release(); actions.release(); status.release(); stage_s.release(); stage_legal.release();
     for (auto& m : stage_meta) m.release();
     stage_pi.release();
@@ -860,23 +865,33 @@ class GameContext {
     }
     if (!mk_src.empty()) {  // TSOneThreadT::_forward for every new leaf: copy of the parent, forward(a)
       const size_t m = mk_src.size();
-      ts_src_.ensure(env_->ctx(), m * 4); ts_dst_.ensure(env_->ctx(), m * 4); ts_act_.ensure(env_->ctx(), m * 8);
-      env_->h2d(ts_src_.get(), mk_src.data(), m * 4);
-      env_->h2d(ts_dst_.get(), mk_dst.data(), m * 4);
-      env_->h2d(ts_act_.get(), mk_act.data(), m * 8);
-      chk(goenv_copy_boards(env_->ctx(), ts_src_.as<int32_t>(), ts_dst_.as<int32_t>(), (int)m, env_->stream()),
+      // the three arrays in pinned blocks of the collector, read by the kernels in place: no copy call (a pageable
+      // hipMemcpyAsync of a few KB costs the host 10 us and more, and a leaf batch had seven of them)
+      c.pin_src.ensure(m * 4); c.pin_dst.ensure(m * 4); c.pin_act.ensure(m * 8);
+      std::memcpy(c.pin_src.as<int32_t>(), mk_src.data(), m * 4);
+      std::memcpy(c.pin_dst.as<int32_t>(), mk_dst.data(), m * 4);
+      std::memcpy(c.pin_act.as<int64_t>(), mk_act.data(), m * 8);
+      chk(goenv_copy_boards(env_->ctx(), c.pin_src.as<int32_t>(), c.pin_dst.as<int32_t>(), (int)m, env_->stream()),
           "goenv_copy_boards");
-      chk(goenv_ply_sel(env_->ctx(), ts_dst_.as<int32_t>(), 0, (int)m, 0u, ts_act_.as<int64_t>(), nullptr, nullptr,
+      chk(goenv_ply_sel(env_->ctx(), c.pin_dst.as<int32_t>(), 0, (int)m, 0u, c.pin_act.as<int64_t>(), nullptr, nullptr,
                         nullptr, nullptr, nullptr, nullptr, env_->stream()), "goenv_ply_sel");
     }
     c.contiguous = true;
     for (int r = 1; r < n; ++r)
       if (c.boards[r] != c.boards[0] + r) { c.contiguous = false; break; }
     const int32_t* d_idx = nullptr;
+    c.idx_pinned = false;
     if (!c.contiguous) {
-      c.idx.ensure(env_->ctx(), (size_t)n * 4);
-      env_->h2d(c.idx.get(), c.boards.data(), (size_t)n * 4);
-      d_idx = c.idx.as<int32_t>();
+      if (mcts_ && leaf_batch(c)) {   // (ends with a synchronise in steps_mcts: the block is free again by the next batch)
+        c.pin_idx.ensure((size_t)n * 4);
+        std::memcpy(c.pin_idx.as<int32_t>(), c.boards.data(), (size_t)n * 4);
+        d_idx = c.pin_idx.as<int32_t>();
+        c.idx_pinned = true;
+      } else {
+        c.idx.ensure(env_->ctx(), (size_t)n * 4);
+        env_->h2d(c.idx.get(), c.boards.data(), (size_t)n * 4);
+        d_idx = c.idx.as<int32_t>();
+      }
     }
     const int32_t* d_aug = nullptr;
     bool st_s = false, st_l = false, st_m[8] = {false, false, false, false, false, false, false, false};
@@ -1141,23 +1156,23 @@ class GameContext {
   void steps_mcts(Collector& c) {
     const int n = (int)c.games.size();
     constexpr int K = 5;
-    const int32_t* d_idx = c.contiguous ? nullptr : c.idx.as<int32_t>();
+    const int32_t* d_idx = c.contiguous ? nullptr : (c.idx_pinned ? c.pin_idx.as<int32_t>() : c.idx.as<int32_t>());
     const int first = c.contiguous ? c.boards[0] : 0;
     const float* d_pi = (const float*)reply_ptr(c, "pi", c.stage_pi, (size_t)n * GOENV_NUM_POINTS * 4);
     auto itv = c.reply.find("V");
     if (!d_pi || itv == c.reply.end())
       throw std::range_error("Steps(): tree search needs \"pi\" and \"V\" in the reply of collector " + std::to_string(c.gid));
-    ts_topa_.ensure(env_->ctx(), (size_t)n * K * 4);
-    ts_topp_.ensure(env_->ctx(), (size_t)n * K * 4);
-    chk(goenv_topk_policy(env_->ctx(), d_idx, first, n, d_pi, nullptr, K, ts_topa_.as<int32_t>(), ts_topp_.as<float>(),
+    // the kernel writes the top-k lists straight into pinned host memory, V is copied into it: one synchronise, no staging
+    c.pin_topa.ensure((size_t)n * K * 4);
+    c.pin_topp.ensure((size_t)n * K * 4);
+    c.pin_v.ensure((size_t)n * 4);
+    chk(goenv_topk_policy(env_->ctx(), d_idx, first, n, d_pi, nullptr, K, c.pin_topa.as<int32_t>(), c.pin_topp.as<float>(),
                           env_->stream()), "goenv_topk_policy");
-    std::vector<int32_t> top_a((size_t)n * K);
-    std::vector<float> top_p((size_t)n * K), value(n);
-    env_->d2h(top_a.data(), ts_topa_.get(), top_a.size() * 4);
-    env_->d2h(top_p.data(), ts_topp_.get(), top_p.size() * 4);
-    if (itv->second.device) env_->d2h(value.data(), itv->second.p, (size_t)n * 4);
+    if (itv->second.device) env_->d2h(c.pin_v.as<float>(), itv->second.p, (size_t)n * 4);
     env_->sync();
-    if (!itv->second.device) std::memcpy(value.data(), itv->second.p, (size_t)n * 4);
+    if (!itv->second.device) std::memcpy(c.pin_v.as<float>(), itv->second.p, (size_t)n * 4);
+    const int32_t* top_a = c.pin_topa.as<int32_t>();
+    const float *top_p = c.pin_topp.as<float>(), *value = c.pin_v.as<float>();
     // The trees of different games share nothing: the games of the batch are expanded and run on
     // to their next leaves in parallel on the host pool (rows of one game stay in row order), then
     // their leaves are queued in game order, so the batches are the same for any number of threads.

@@ -5,6 +5,7 @@
 #pragma once
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <exception>
@@ -40,8 +41,8 @@ class WorkerPool {
   ~WorkerPool() {
     {
       std::lock_guard<std::mutex> lk(m_);
-      stop_ = true;
-      generation_ += 1;
+      stop_.store(true);
+      generation_.fetch_add(1, std::memory_order_release);
     }
     wake_.notify_all();
     for (auto& t : workers_) t.join();
@@ -64,19 +65,28 @@ class WorkerPool {
       fn_ = &fn;
       count_ = count;
       next_.store(0);
-      active_ = (int)workers_.size();
+      active_.store((int)workers_.size());
       error_ = nullptr;
-      generation_ += 1;
+      generation_.fetch_add(1, std::memory_order_release);
     }
-    wake_.notify_all();
+    wake_.notify_all();   // (for the workers that have gone to sleep; the others are polling)
     work();
-    std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [this] { return active_ == 0; });
+    // the workers end within one fn call of this thread's end: poll first, sleep only if that takes long
+    for (int spin = 0; active_.load(std::memory_order_acquire) != 0; ++spin) {
+      if (spin < (1 << 16)) {
+        relax();
+      } else {
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return active_.load() == 0; });
+      }
+    }
     fn_ = nullptr;
     if (error_) std::rethrow_exception(error_);
   }
 
  private:
+  static void relax() { __builtin_ia32_pause(); }
+
   void work() {
     for (;;) {
       const int i = next_.fetch_add(1);
@@ -90,21 +100,29 @@ class WorkerPool {
     }
   }
 
+  // A worker polls for the next batch for a while before it sleeps on the condition variable: the batches of a running
+  // search follow one another within a few hundred microseconds, and waking a sleeping thread costs tens of them.
   void loop() {
     unsigned long seen = 0;
     for (;;) {
-      {
+      bool got = false;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int spin = 0;; ++spin) {
+        if (generation_.load(std::memory_order_acquire) != seen) { got = true; break; }
+        relax();
+        if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) break;
+      }
+      if (!got) {
         std::unique_lock<std::mutex> lk(m_);
-        wake_.wait(lk, [&] { return generation_ != seen; });
-        seen = generation_;
-        if (stop_) return;
+        wake_.wait(lk, [&] { return generation_.load() != seen; });
       }
+      seen = generation_.load(std::memory_order_acquire);
+      if (stop_.load()) return;
       work();
-      {
+      if (active_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
         std::lock_guard<std::mutex> lk(m_);
-        active_ -= 1;
+        done_.notify_one();
       }
-      done_.notify_one();
     }
   }
 
@@ -112,10 +130,10 @@ class WorkerPool {
   std::mutex m_;
   std::condition_variable wake_, done_;
   const std::function<void(int)>* fn_ = nullptr;
-  std::atomic<int> next_{0};
-  int count_ = 0, active_ = 0;
-  unsigned long generation_ = 0;
-  bool stop_ = false;
+  std::atomic<int> next_{0}, active_{0};
+  int count_ = 0;
+  std::atomic<unsigned long> generation_{0};
+  std::atomic<bool> stop_{false};
   std::exception_ptr error_;
 };
 

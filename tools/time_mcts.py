@@ -93,6 +93,7 @@ def run_ours(args):
             "seconds": dt, "evaluations_per_s": n / dt, "rows_per_batch": n / max(1, batches), "moves_played": moves,
             "us_per_batch": dt / max(1, batches) * 1e6,
             "host_us_per_batch": (ht["wait_us"] + ht["steps_us"]) / max(1, ht["waits"]),
+            "host_wait_us_per_batch": ht["wait_us"] / max(1, ht["waits"]), "host_steps_us_per_batch": ht["steps_us"] / max(1, ht["steps"]),
             "host_threads": int(os.environ.get("GOENV_HOST_THREADS", "0")) or min(16, len(os.sched_getaffinity(0)))}
 
 
